@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- greedy iterations/sec + achieved HBM GB/s of the selection loop on MI355X.
+
+A *step* is one full `select all` run of the greedy loop (utmos/select.py:69-112) over the synthetic
+10M-variant x 2,504-sample bit matrix (BASELINE.json configs[1]), matrix already resident in HBM.
+`value` = greedy iterations per second over the K timed steps (all ranks, max time over ranks).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          # one rank per GPU; samples sharded; RCCL exchange
+
+With N > 1 the same 10M x 2,504 problem is sharded over the sample axis (strong scaling): every
+iteration ends with one ncclAllGather of {best record, best column} per rank.  No torch is imported:
+ranks find each other through RANK/LOCAL_RANK/WORLD_SIZE and a rendezvous file for the ncclUniqueId.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--n-var", type=int, default=10_000_000)
+    p.add_argument("--n-samp", type=int, default=2504)
+    p.add_argument("--select", type=int, default=-1, help="samples to select per step (-1 = all)")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--af", action="store_true", help="configs[2]: float32 AF weighting")
+    p.add_argument("--chunk-vars", type=int, default=0, help="split the variant axis into chunks of this many variants")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-vars", type=int, default=300_000)
+    p.add_argument("--no-roofline-pass", action="store_true")
+    return p.parse_args()
+
+
+def rendezvous_id(rank, world, make_id):
+    """Rank 0 publishes the 128-byte ncclUniqueId in a file every rank of this launch can name."""
+    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"utmos_amd_ncclid_{key}")
+    if rank == 0:
+        uid = make_id()
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    deadline = time.time() + 300
+    while time.time() < deadline:
+        try:
+            with open(path, "rb") as fh:
+                uid = fh.read()
+            if len(uid) == 128:
+                return uid, path
+        except FileNotFoundError:
+            pass
+        time.sleep(0.05)
+    raise RuntimeError(f"rank {rank}: no ncclUniqueId at {path} after 300 s")
+
+
+def cpu_baseline(args, device_mod):
+    """The reference's algorithm on the host, on a bounded sample of the same synthetic workload:
+    oracle.score_rowloop = the per-row numpy loop of utmos/select.py:33-48, single thread, first 3
+    iterations on the first `cpu_sample_vars` variants; rate scaled to the full variant count
+    (time per iteration is linear in rows).  Second line: the packed C oracle with OpenMP."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_util as ou
+    n_var = min(args.cpu_sample_vars, args.n_var)
+    with device_mod.DeviceMatrix(args.n_samp, device=0) as m:
+        c = m.add_chunk(n_var)
+        m.synth_fill(c, seed=args.seed)
+        cols = m.download_columns(c)
+    bits = np.unpackbits(cols.view(np.uint8), axis=1, bitorder="little")[:, :n_var]
+    dense = np.ascontiguousarray(bits.T).astype(bool)
+    del bits
+    state = np.ones(args.n_samp, np.uint8)
+    iters = 3
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        best, _new = ou.npo.score_rowloop(dense, state)
+        state[best] = 0
+    dt = time.perf_counter() - t0
+    scale = n_var / args.n_var
+    port = {"value": iters / dt * scale, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"first {iters} greedy iterations on the first {n_var} of {args.n_var} synthetic variants x "
+                      f"{args.n_samp} samples (numpy row loop, {dt:.1f} s); rate scaled by {scale:.4g} to the full variant count",
+            "host_cpus": os.cpu_count()}
+    threads = min(os.cpu_count() or 1, 16)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    t0 = time.perf_counter()
+    k = 40
+    idx, _, _ = ou.c_greedy(cols, n_var, np.ones(args.n_samp, np.uint8), k_max=k, omp=True)
+    dt2 = time.perf_counter() - t0
+    bitset = {"value": len(idx) / dt2 * scale, "unit": "iterations/s", "cores": threads, "kind": "port",
+              "sample": f"first {len(idx)} iterations, packed C bitset oracle with OpenMP, same sample, scaled the same way"}
+    return port, bitset
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 needs one process per GPU: launch with python -m torch.distributed.run "
+                             "--nproc-per-node N (see module docstring)")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    from utmos_amd import device
+
+    n_total = args.n_samp
+    first = rank * n_total // world
+    n_local = (rank + 1) * n_total // world - first
+    m = device.DeviceMatrix(n_total, device=local_rank, first_sample=first, n_local=n_local)
+    chunk_vars = args.chunk_vars or args.n_var
+    v0 = 0
+    t_gen = time.perf_counter()
+    while v0 < args.n_var:
+        nv = min(chunk_vars, args.n_var - v0)
+        c = m.add_chunk(nv)
+        m.synth_fill(c, seed=args.seed, first_var_global=v0)
+        if args.af:
+            _, af = device.synth_host(args.seed, nv, n_total, first_var_global=v0, want_cols=False)
+            m.set_af(c, af)
+        v0 += nv
+    t_gen = time.perf_counter() - t_gen
+    if world > 1:
+        uid, id_path = rendezvous_id(rank, world, device.DeviceMatrix.comm_unique_id)
+        m.comm_init(rank, world, uid)
+    k_sel = n_total if args.select < 0 else min(args.select, n_total)
+
+    def one_step():
+        m.reset()
+        return m.run(k_sel)
+
+    for _ in range(args.warmup):
+        one_step()
+    m.allreduce_max(0.0)  # barrier (run() returns only after its stream has drained)
+    t0 = time.perf_counter()
+    iters = 0
+    loop_ms = 0.0
+    for _ in range(args.steps):
+        idx, new, _ = one_step()
+        iters += len(idx)
+        loop_ms += m.stats()["loop_ms"]
+    elapsed = time.perf_counter() - t0
+    elapsed = m.allreduce_max(elapsed)
+    st = m.stats()
+    algo_bytes_step = st["algo_bytes"]          # since the last reset = one step, this rank's shard
+    tot_captured = st["tot_captured"]
+
+    roofline = None
+    if not args.no_roofline_pass:
+        # same step once more with every scoring launch bracketed by HIP events on its own stream
+        m.set_profile(True)
+        one_step()
+        ps = m.stats()
+        m.set_profile(False)
+        if ps["score_ms"] > 0:
+            achieved = ps["algo_bytes"] / (ps["score_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                        "kernel": "k_score_afq" if args.af else "k_score_int",
+                        "launches": ps["score_launches"],
+                        "avg_launch_us": ps["score_ms"] * 1e3 / max(1, ps["score_launches"]),
+                        "algo_bytes_per_launch": ps["algo_bytes"] / max(1, ps["score_launches"]),
+                        "rank": rank}
+
+    cpu = bitset = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, bitset = cpu_baseline(args, device)
+
+    if world > 1 and rank == 0:
+        try:
+            os.remove(id_path)
+        except OSError:
+            pass
+    if rank != 0:
+        m.close()
+        return
+    value = iters / elapsed
+    whole_loop_gbps = algo_bytes_step * world * args.steps / elapsed / 1e9   # shards are equal-sized to within one sample
+    line = {
+        "metric": "greedy iterations/sec + achieved HBM GB/s, 10M variants x 2.5k samples",
+        "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32+u64" if args.af else "u64", "data": "synthetic",
+        "config": {"workload": f"synthetic {args.n_var} variants x {n_total} samples bit-matrix, select "
+                               f"{'all' if args.select < 0 else k_sel}{', --af float32' if args.af else ''}",
+                   "n_var": args.n_var, "n_samp": n_total, "iterations_per_step": iters // max(1, args.steps),
+                   "tot_captured": tot_captured, "chunks": st["n_chunks"], "seed": args.seed,
+                   "sharding": f"sample axis over {world} GPU(s), one ncclAllGather per iteration" if world > 1 else "none",
+                   "generator_s": round(t_gen, 3)},
+        "hbm_gbps_whole_loop": whole_loop_gbps, "hbm_frac_whole_loop": whole_loop_gbps / (HBM_PEAK_GBPS * world),
+        "device_loop_ms_per_step": loop_ms / max(1, args.steps),
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_bitset_baseline": bitset,
+    }
+    print(json.dumps(line))
+    m.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+/* utmos_hip.h -- C ABI of libutmos_hip.so: greedy maximum-coverage selection on MI355X (gfx950).
+ *
+ * The reference (ACEnglish/utmos v2.2.0) has no FFI/plugin interface; its only seam for this
+ * path is the Python call chain
+ *
+ *     run_selection   utmos/select.py:147-195
+ *       greedy_select utmos/select.py:69-137   (generator; mutates sample_mask in place, :100)
+ *         calculate_scores utmos/select.py:24-53  -> (idx, new_count) | (None, None)
+ *
+ * so the entry points below are what a ctypes binding inside utmos/select.py would call in place
+ * of calculate_scores / greedy_select (INTEGRATION.md shows that binding).  Plain pointers and
+ * sizes only; no Python, numpy or torch types.
+ *
+ * Conventions
+ *   - every function returns 0 (UTM_OK) or a negative UTM_E* code; utm_last_error() gives the text
+ *     of the last failure on the calling thread.
+ *   - host buffers are borrowed for the duration of the call; device memory belongs to the context.
+ *   - one context = one GPU = one contiguous shard [first_sample, first_sample + n_local) of the
+ *     sample axis.  A context is not thread-safe; it owns one HIP stream.
+ *   - the matrix is a list of *chunks* along the variant axis (the replacement for the reference's
+ *     row-chunked hdf5 store, select.py:198-231).  Inside a chunk every sample is one column:
+ *     W = ceil(n_var/64) little-endian uint64 words, variant v of the chunk = bit (v & 63) of word
+ *     (v >> 6), zero padded.
+ *   - sample states follow select.py:169-179: 1 selectable, 0 already used (covers), 2 excluded.
+ */
+#ifndef UTMOS_HIP_H
+#define UTMOS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UTM_OK 0
+#define UTM_EINVAL (-1)   /* bad argument */
+#define UTM_EHIP (-2)     /* HIP runtime error */
+#define UTM_ENOMEM (-3)   /* allocation failed */
+#define UTM_ESTATE (-4)   /* call not valid in the context's current state */
+#define UTM_ECOMM (-5)    /* RCCL error / RCCL not available */
+
+#define UTM_ABI_VERSION 1
+
+typedef struct utm_ctx utm_ctx;
+
+/* AF value modes (utm_set_af).  F32 restates the reference's hdf5 store (float32 presence*AF,
+ * select.py:218-223); F64 its in-memory matrix (float64, select.py:314-321). */
+#define UTM_AF_NONE 0
+#define UTM_AF_F32 1
+#define UTM_AF_F64 2
+
+/* utm_ctx_create flags */
+#define UTM_FLAG_PROFILE_EVENTS 1u /* bracket every scoring launch with HIP events (utm_stats.score_ms) */
+#define UTM_FLAG_AF_SEQUENTIAL 2u  /* never use the order-independent fixed-point form for F32 AF */
+
+/* One local-best record, as exchanged between shards (64 bytes). */
+typedef struct utm_record {
+    double score;      /* final (masked, weighted) score of the shard's best selectable sample */
+    int64_t idx;       /* its GLOBAL sample index, or -1 when the shard has no selectable sample */
+    int64_t new_count; /* variants it would newly capture (counts[use], select.py:49) */
+    int64_t pad[5];
+} utm_record;
+
+typedef struct utm_stats {
+    int64_t iterations;      /* greedy iterations completed since the last utm_reset */
+    int64_t tot_captured;    /* running total of new_count */
+    int64_t score_launches;  /* scoring-kernel launches since the last utm_reset */
+    double score_ms;         /* summed HIP-event time of those launches (UTM_FLAG_PROFILE_EVENTS), else 0 */
+    double loop_ms;          /* HIP-event time of the last utm_run (stream time, first launch to last) */
+    int64_t algo_bytes;      /* algorithmic HBM bytes of the iterations since the last utm_reset */
+    int32_t af_mode;         /* UTM_AF_* in effect */
+    int32_t af_fixed_point;  /* 1 when F32 AF runs as exact int64 fixed point, 0 when sequential */
+    int32_t af_q;            /* fixed-point scale: scores = sum / 2^q */
+    int32_t n_chunks;
+} utm_stats;
+
+const char *utm_last_error(void);
+int utm_abi_version(void);
+int utm_device_count(int *n);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_sample, uint32_t n_samp_local,
+                   uint32_t flags, utm_ctx **out);
+int utm_ctx_destroy(utm_ctx *ctx);
+
+/* ---- matrix (select.py:275-321 builds the reference's; here it is built in HBM) -------------- */
+/* Append an all-zero chunk of n_var variants; returns its index in *chunk. */
+int utm_add_chunk(utm_ctx *ctx, uint64_t n_var, int32_t *chunk);
+/* Upload n_cols whole columns of a chunk, local column first_col onwards.
+ * cols[c * stride_words + w], stride_words >= ceil(n_var/64). */
+int utm_upload_columns(utm_ctx *ctx, int32_t chunk, uint32_t first_col, uint32_t n_cols,
+                       const uint64_t *cols, uint64_t stride_words);
+/* Upload n_rows variants in the reference's own packing (numpy.packbits(axis=1), MSB first,
+ * convert.py:85): rows[r * row_stride_bytes + (s >> 3)] bit (7 - (s & 7)) = GLOBAL sample s.
+ * The bit transpose to column-major runs on the GPU.  first_var must be a multiple of 64. */
+int utm_upload_rows_packed(utm_ctx *ctx, int32_t chunk, uint64_t first_var, uint64_t n_rows,
+                           const uint8_t *rows, uint64_t row_stride_bytes);
+int utm_download_columns(utm_ctx *ctx, int32_t chunk, uint32_t first_col, uint32_t n_cols,
+                         uint64_t *cols, uint64_t stride_words);
+/* Per-sample carrier totals over all chunks (var_count, select.py:281-284), n_samp_local values. */
+int utm_var_count(utm_ctx *ctx, int64_t *out);
+/* Seeded synthetic chunk contents generated on the GPU (bench/test input, DESIGN.md "Synthetic input"). */
+int utm_synth_fill(utm_ctx *ctx, int32_t chunk, uint64_t seed, uint64_t first_var_global);
+/* The same generator on the host (no GPU call): columns of samples [first, first+n) and/or per-variant AF. */
+int utm_synth_host(uint64_t seed, uint64_t first_var_global, uint64_t n_var, uint32_t n_samp_total,
+                   uint32_t first_sample, uint32_t n_samp, uint64_t *cols, uint64_t stride_words,
+                   float *af_out);
+
+/* ---- scoring options ------------------------------------------------------------------------ */
+/* state[n_samp_total]: 1 selectable / 0 used / 2 excluded.  Implies utm_reset. */
+int utm_set_sample_state(utm_ctx *ctx, const uint8_t *state);
+/* weights[n_samp_total] (select.py:181-187) or NULL for none.  Must be finite. */
+int utm_set_weights(utm_ctx *ctx, const double *weights);
+/* Per-variant AF of one chunk: mode UTM_AF_F32 (const float*) or UTM_AF_F64 (const double*), n_var
+ * values, finite and >= 0.  All chunks must use the same mode.  UTM_AF_NONE with af == NULL clears. */
+int utm_set_af(utm_ctx *ctx, int32_t chunk, int mode, const void *af);
+
+/* ---- the greedy loop ------------------------------------------------------------------------ */
+/* Restart: covered := OR of the columns of used (state 0) local samples, tot_captured := 0. */
+int utm_reset(utm_ctx *ctx);
+/* One iteration = calculate_scores (select.py:24-53) + the winner update (select.py:99-100).
+ * *idx = global sample index or -1 for the reference's (None, None). */
+int utm_step(utm_ctx *ctx, int64_t *idx, int64_t *new_count, double *score);
+/* Up to k_max iterations, device resident; stops like greedy_select (select.py:93-96, :110-112).
+ * Outputs need k_max entries (score_out may be NULL); *n_done = rows produced. */
+int utm_run(utm_ctx *ctx, int64_t k_max, int64_t *idx_out, int64_t *new_out, double *score_out,
+            int64_t *n_done);
+/* Scores of the NEXT iteration without selecting: counts[n_local] (new variants per local sample,
+ * 0 for non-selectable) and final scores[n_local].  Either may be NULL.  Parity/debug aid. */
+int utm_peek_scores(utm_ctx *ctx, int64_t *counts, double *scores);
+/* Current covered mask of a chunk (all pending updates applied), ceil(n_var/64) words. */
+int utm_get_covered(utm_ctx *ctx, int32_t chunk, uint64_t *out);
+int utm_get_stats(utm_ctx *ctx, utm_stats *out);
+/* Switch per-launch HIP-event timing of the scoring kernels on/off (same as UTM_FLAG_PROFILE_EVENTS). */
+int utm_set_profile(utm_ctx *ctx, int32_t on);
+
+/* ---- sharded operation: building blocks for any transport ------------------------------------- */
+/* Score locally and report this shard's best candidate; nothing is selected. */
+int utm_local_best(utm_ctx *ctx, utm_record *rec);
+/* Words per sample summed over chunks (length of a whole-column buffer). */
+int utm_column_words(utm_ctx *ctx, uint64_t *n_words);
+/* Concatenated chunk columns of a LOCAL sample (global index), utm_column_words() words. */
+int utm_get_column(utm_ctx *ctx, int64_t global_idx, uint64_t *out);
+/* Apply one exchanged decision: recs[n_ranks] are all shards' records in rank order; the winner is
+ * chosen exactly as the fused path does (score desc, index asc).  winner_col is the winner's whole
+ * column, or NULL when the winner is local to this context.  Outputs as utm_step. */
+int utm_apply_records(utm_ctx *ctx, const utm_record *recs, int32_t n_ranks, const uint64_t *winner_col,
+                      int64_t *idx, int64_t *new_count, double *score);
+
+/* ---- RCCL (one process per GPU; ids are exchanged by the caller) ------------------------------ */
+#define UTM_UNIQUE_ID_BYTES 128
+int utm_comm_get_unique_id(void *id);
+/* After this, utm_step / utm_run exchange records + winner columns with one ncclAllGather per iteration. */
+int utm_comm_init(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *id);
+int utm_comm_allreduce_max(utm_ctx *ctx, double *value); /* in place; also a barrier */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UTMOS_HIP_H */

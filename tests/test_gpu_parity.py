@@ -1,0 +1,270 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Bit-exact bar: sample order, new_count and -- for AF modes -- the float64 score itself."""
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from oracle_util import npo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from utmos_amd import _native as nat
+    assert nat.device_count() >= 1, "no GPU visible"
+    from utmos_amd import device
+    return device
+
+
+def make_matrix(dev, cols, n_var, **kw):
+    m = dev.DeviceMatrix(cols.shape[0], **kw)
+    c = m.add_chunk(n_var)
+    m.upload_columns(c, cols)
+    return m
+
+
+def check_run(dev, dense, state=None, weights=None, af=None, k=None, chunks=None, **kw):
+    n_var, n_samp = dense.shape
+    state = np.ones(n_samp, np.uint8) if state is None else state
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, state, weights, af, k_max=k)
+    m = dev.DeviceMatrix(n_samp, **kw)
+    try:
+        bounds = [0, n_var] if chunks is None else chunks
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            c = m.add_chunk(hi - lo)
+            m.upload_columns(c, npo.pack_columns(dense[lo:hi]))
+            if af is not None:
+                m.set_af(c, af[lo:hi])
+        m.set_state(state)
+        m.set_weights(weights)
+        got = m.run(n_samp if k is None else k)
+        stats = m.stats()
+    finally:
+        m.close()
+    assert got[0].tolist() == exp[0].tolist()
+    assert got[1].tolist() == exp[1].tolist()
+    assert got[2].tolist() == exp[2].tolist()          # float64 scores, bit for bit
+    return got, stats
+
+
+def test_synth_device_equals_host(dev):
+    n_var, n_samp = 5000, 77
+    cols, _ = dev.synth_host(3, n_var, n_samp)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.synth_fill(c, seed=3)
+        assert (m.download_columns(c) == cols).all()
+        bits = np.unpackbits(cols.view(np.uint8), axis=1, bitorder="little")[:, :n_var]
+        assert (m.var_count() == bits.sum(axis=1)).all()
+
+
+def test_upload_download_roundtrip_and_row_transpose(dev):
+    rng = np.random.default_rng(5)
+    n_var, n_samp = 1000, 203          # neither a multiple of 64 nor of 8
+    dense = ou.random_dense(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    with make_matrix(dev, cols, n_var) as m:
+        assert (m.download_columns(0) == cols).all()
+    rows = np.packbits(dense, axis=1)   # the reference's own packing (convert.py:85)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_rows_packed(c, rows)
+        assert (m.download_columns(c) == cols).all()
+    # a shard that starts at a sample that is not byte aligned
+    with dev.DeviceMatrix(n_samp, first_sample=67, n_local=100) as m:
+        c = m.add_chunk(n_var)
+        m.upload_rows_packed(c, rows)
+        assert (m.download_columns(c) == cols[67:167]).all()
+
+
+@pytest.mark.parametrize("n_var,n_samp", [(1, 1), (63, 3), (64, 4), (65, 5), (1000, 130), (8192, 64), (8193, 257),
+                                          (20000, 33)])
+def test_int_mode_select_all(dev, n_var, n_samp):
+    rng = np.random.default_rng(n_var + n_samp)
+    check_run(dev, ou.random_dense(rng, n_var, n_samp))
+
+
+def test_int_mode_large_tiles(dev):
+    # enough variants for full 32-step tiles plus a ragged last tile
+    rng = np.random.default_rng(11)
+    n_var, n_samp = 64 * 128 * 70 + 777, 24
+    dense = rng.random((n_var, n_samp)) < 0.02
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    check_run(dev, dense)
+
+
+def test_exclude_used_and_k(dev):
+    rng = np.random.default_rng(2)
+    dense = ou.random_dense(rng, 3000, 90)
+    state = np.ones(90, np.uint8)
+    state[[3, 17, 40]] = 2          # excluded: never selected, never cover
+    state[[5, 60]] = 0              # used from the start: cover from the first iteration
+    check_run(dev, dense, state=state, k=25)
+
+
+def test_weights_including_negative_and_zero(dev):
+    rng = np.random.default_rng(4)
+    dense = ou.random_dense(rng, 2500, 70)
+    w = rng.choice([0.0, 0.25, 1.0, 3.0, 10.0], 70)
+    check_run(dev, dense, weights=w)
+    w2 = np.where(np.arange(70) % 2 == 0, -1.0, 1.0)
+    state = np.ones(70, np.uint8)
+    state[0] = 2
+    check_run(dev, dense, weights=w2, state=state)
+    check_run(dev, dense, weights=-np.ones(70))     # all negative, nothing masked: still selects
+
+
+def test_ties_lowest_index(dev):
+    dense = np.zeros((256, 8), dtype=bool)
+    for s in range(8):
+        dense[32 * s:32 * s + 32, s] = True        # eight identical scores every iteration
+    got, _ = check_run(dev, dense)
+    assert got[0].tolist() == list(range(8))
+
+
+def test_zero_score_exhaustion(dev):
+    # variants carried only by an excluded sample can never be captured: loop ends on score 0
+    dense = np.zeros((10, 4), dtype=bool)
+    dense[:4, 0] = True
+    dense[2:6, 1] = True
+    dense[6:, 3] = True
+    dense[0, 2] = True
+    state = np.array([1, 1, 1, 2], np.uint8)
+    got, _ = check_run(dev, dense, state=state)
+    assert got[0].tolist() == [0, 1]
+
+
+@pytest.mark.parametrize("mode", ["f32", "f32_seq", "f64"])
+def test_af_modes(dev, mode):
+    rng = np.random.default_rng(9)
+    n_var, n_samp = 9000, 140
+    dense = ou.random_dense(rng, n_var, n_samp)
+    af = dense.sum(axis=1) / (2.0 * n_samp)
+    af[::97] = 0.0                                  # AF == 0 rows vanish from the reference's float matrix
+    if mode != "f64":
+        af = af.astype(np.float32)
+    w = rng.choice([0.5, 1.0, 2.0], n_samp)
+    _, stats = check_run(dev, dense, af=af, af_sequential=(mode == "f32_seq"))
+    assert stats["af_fixed_point"] == (1 if mode == "f32" else 0)
+    check_run(dev, dense, af=af, weights=w, af_sequential=(mode == "f32_seq"), k=40)
+
+
+def test_af_f32_falls_back_when_not_exactly_summable(dev):
+    rng = np.random.default_rng(10)
+    dense = ou.random_dense(rng, 2000, 50)
+    af = rng.random(2000).astype(np.float32)
+    af[0] = np.float32(1e-30)                       # tiny exponent: q too large for exact fixed point
+    _, stats = check_run(dev, dense, af=af)
+    assert stats["af_fixed_point"] == 0
+
+
+def test_multi_chunk_equals_single_chunk(dev):
+    rng = np.random.default_rng(12)
+    n_var, n_samp = 30000, 60
+    dense = ou.random_dense(rng, n_var, n_samp)
+    af64 = dense.sum(axis=1) / (2.0 * n_samp)
+    bounds = [0, 777, 9000, 9064, 30000]
+    check_run(dev, dense, chunks=bounds)
+    check_run(dev, dense, chunks=bounds, af=af64.astype(np.float32))
+    check_run(dev, dense, chunks=bounds, af=af64)
+
+
+def test_step_peek_and_covered(dev):
+    rng = np.random.default_rng(13)
+    n_var, n_samp = 5000, 40
+    dense = ou.random_dense(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    state = np.ones(n_samp, np.uint8)
+    with make_matrix(dev, cols, n_var) as m:
+        covered = np.zeros(cols.shape[1], np.uint64)
+        for _ in range(6):
+            best, cnt, sc = ou.c_score(cols, n_var, state)
+            counts, scores = m.peek_scores()
+            assert counts.tolist() == cnt.tolist() and scores.tolist() == sc.tolist()
+            got = m.step()
+            assert got is not None and got[0] == best and got[1] == cnt[best]
+            state[best] = 0
+            covered |= cols[best]
+            assert (m.covered(0) == covered).all()
+
+
+def test_golden_fixtures_through_the_device(dev):
+    cases = ou.golden_cases()
+    for name in ("select_multi", "select_exclude", "select_af", "select_af_h5", "select_weightsaf", "select_tiny"):
+        case = cases[name]
+        kw = ou.case_kwargs(case["args"])
+        parts = [ou.load_part(n) for n in case["inputs"]]
+        samples = parts[0]["samples"].astype(str)
+        with dev.DeviceMatrix(len(samples)) as m:
+            for p in parts:
+                keep = p["GT"].any(axis=1)
+                c = m.add_chunk(int(keep.sum()))
+                m.upload_rows_packed(c, p["GT"][keep])
+                if kw.get("af"):
+                    af = p["AF"][keep]
+                    m.set_af(c, af.astype(np.float32) if kw.get("af_dtype") == "f32" else af)
+            var_count = m.var_count()
+            m.set_state(npo.initial_state(samples, kw.get("subset"), kw.get("exclude")))
+            m.set_weights(npo.weight_vector(samples, kw.get("weights")))
+            k = npo.resolve_count(len(samples), kw.get("count", 0.02))
+            idx, new, _ = m.run(k)
+            n_var = m.shape[0]
+        tot = np.cumsum(new)
+        text = npo.HEADER + "".join(
+            npo.format_row([samples[i], int(var_count[i]), int(n), int(t), round(t / n_var, 4)])
+            for i, n, t in zip(idx, new, tot))
+        assert text == ou.golden_text(case), name
+
+
+def test_sharded_building_blocks_two_shards_one_gpu(dev):
+    """Two contexts hold half the samples each; records + winner columns are exchanged by the test.
+    Same decisions as one context holding everything."""
+    rng = np.random.default_rng(14)
+    n_var, n_samp = 6000, 50
+    dense = ou.random_dense(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    w = rng.choice([1.0, 2.0], n_samp)
+    state = np.ones(n_samp, np.uint8)
+    state[7] = 2
+    exp = ou.c_greedy(cols, n_var, state, w)
+    shards = []
+    for first, n in ((0, 21), (21, 29)):
+        m = dev.DeviceMatrix(n_samp, first_sample=first, n_local=n)
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols[first:first + n])
+        m.set_state(state)
+        m.set_weights(w)
+        shards.append(m)
+    got_idx, got_new = [], []
+    for _ in range(n_samp):
+        recs = [m.local_best() for m in shards]
+        cand = [(-r[0], r[1], i) for i, r in enumerate(recs) if r[1] >= 0]
+        if not cand:
+            break
+        owner = min(cand)[2]
+        col = shards[owner].get_column(recs[owner][1])
+        outs = [m.apply_records(recs, None if i == owner else col) for i, m in enumerate(shards)]
+        assert outs[0] == outs[1]
+        if outs[0] is None:
+            break
+        got_idx.append(outs[0][0])
+        got_new.append(outs[0][1])
+    for m in shards:
+        m.close()
+    assert got_idx == exp[0].tolist() and got_new == exp[1].tolist()
+
+
+def test_rccl_single_rank_path(dev):
+    """The RCCL code path with a 1-rank communicator (all this box can host)."""
+    rng = np.random.default_rng(15)
+    n_var, n_samp = 4000, 30
+    dense = ou.random_dense(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8))
+    with make_matrix(dev, cols, n_var) as m:
+        m.comm_init(0, 1, dev.DeviceMatrix.comm_unique_id())
+        assert m.allreduce_max(3.5) == 3.5
+        got = m.run(n_samp)
+    assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()

@@ -1,0 +1,102 @@
+"""ctypes binding of libutmos_hip.so (C ABI: include/utmos_hip.h).  No torch, no cffi."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libutmos_hip.so")
+
+UTM_OK = 0
+AF_NONE, AF_F32, AF_F64 = 0, 1, 2
+FLAG_PROFILE_EVENTS = 1
+FLAG_AF_SEQUENTIAL = 2
+UNIQUE_ID_BYTES = 128
+
+
+class NativeError(RuntimeError):
+    """A libutmos_hip call failed (code, message from utm_last_error)."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libutmos_hip error {code}: {message}")
+        self.code = code
+
+
+class Record(ctypes.Structure):
+    _fields_ = [("score", ctypes.c_double), ("idx", ctypes.c_int64), ("new_count", ctypes.c_int64),
+                ("pad", ctypes.c_int64 * 5)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int64), ("tot_captured", ctypes.c_int64),
+                ("score_launches", ctypes.c_int64), ("score_ms", ctypes.c_double),
+                ("loop_ms", ctypes.c_double), ("algo_bytes", ctypes.c_int64),
+                ("af_mode", ctypes.c_int32), ("af_fixed_point", ctypes.c_int32),
+                ("af_q", ctypes.c_int32), ("n_chunks", ctypes.c_int32)]
+
+
+_P = ctypes.c_void_p
+_U64, _U32, _I32, _I64 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int64
+
+# name -> argtypes, exactly the prototypes of include/utmos_hip.h (tests/test_abi.py checks the list)
+PROTOTYPES = {
+    "utm_abi_version": [],
+    "utm_device_count": [ctypes.POINTER(ctypes.c_int)],
+    "utm_ctx_create": [ctypes.c_int, _U32, _U32, _U32, _U32, ctypes.POINTER(_P)],
+    "utm_ctx_destroy": [_P],
+    "utm_add_chunk": [_P, _U64, ctypes.POINTER(_I32)],
+    "utm_upload_columns": [_P, _I32, _U32, _U32, _P, _U64],
+    "utm_upload_rows_packed": [_P, _I32, _U64, _U64, _P, _U64],
+    "utm_download_columns": [_P, _I32, _U32, _U32, _P, _U64],
+    "utm_var_count": [_P, _P],
+    "utm_synth_fill": [_P, _I32, _U64, _U64],
+    "utm_synth_host": [_U64, _U64, _U64, _U32, _U32, _U32, _P, _U64, _P],
+    "utm_set_sample_state": [_P, _P],
+    "utm_set_weights": [_P, _P],
+    "utm_set_af": [_P, _I32, ctypes.c_int, _P],
+    "utm_reset": [_P],
+    "utm_step": [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_double)],
+    "utm_run": [_P, _I64, _P, _P, _P, ctypes.POINTER(_I64)],
+    "utm_peek_scores": [_P, _P, _P],
+    "utm_get_covered": [_P, _I32, _P],
+    "utm_get_stats": [_P, ctypes.POINTER(Stats)],
+    "utm_set_profile": [_P, _I32],
+    "utm_local_best": [_P, ctypes.POINTER(Record)],
+    "utm_column_words": [_P, ctypes.POINTER(_U64)],
+    "utm_get_column": [_P, _I64, _P],
+    "utm_apply_records": [_P, ctypes.POINTER(Record), _I32, _P, ctypes.POINTER(_I64), ctypes.POINTER(_I64),
+                          ctypes.POINTER(ctypes.c_double)],
+    "utm_comm_get_unique_id": [_P],
+    "utm_comm_init": [_P, _I32, _I32, _P],
+    "utm_comm_allreduce_max": [_P, ctypes.POINTER(ctypes.c_double)],
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once.  Missing library = hard error (there is no CPU path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C utmos_amd/csrc` (hipcc, --offload-arch=gfx950).  utmos_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        handle.utm_last_error.restype = ctypes.c_char_p
+        handle.utm_last_error.argtypes = []
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_int
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != UTM_OK:
+        raise NativeError(code, lib().utm_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib().utm_device_count(ctypes.byref(n)))
+    return n.value

@@ -1,0 +1,499 @@
+// Device code of libutmos_hip.so -- hand-written for gfx950 (CDNA4, wave64).  No portability layer.
+//
+// Data layout: inside a chunk every local sample is one column of `wp` uint64 words
+// (wp = ceil(n_var/64) rounded up to 128 words = 1 KiB, zero padded); cols[s * wp + w].  One wave
+// instruction reads 64 lanes x 16 B = 1 KiB of ONE column, so every HBM access of the scoring
+// kernels is a full, aligned, contiguous KiB.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "synth_hash.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));  // one global_load_dwordx4 / ds_read_b128
+
+#define UTM_HDR_WORDS 8  // one utm_record (64 B) in front of every exchanged column
+#define UTM_STEP_WORDS 128  // words one wave instruction covers (64 lanes x 2)
+
+struct IterState {
+    int done;        // loop finished: every later launch returns at once
+    int prev_valid;  // a winner column still has to be OR-ed into `covered`
+    int prev_local;  // its local column index, or -1: take it from exchange slot prev_rank
+    int prev_rank;
+    unsigned n_active;  // selectable local samples = length of act[]
+    unsigned best_pos;  // position in act[] of this shard's best of the current iteration
+    i64 iter;           // rows produced so far
+    i64 tot;            // tot_captured
+    i64 n_active_total; // selectable samples over all shards
+};
+
+struct Rec {  // == utm_record
+    double score;
+    i64 idx;
+    i64 new_count;
+    i64 pad[5];
+};
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ i64 wave_sum_i64(i64 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Winner column of the previous iteration for words [w0, ...) of a chunk, or nullptr.
+__device__ __forceinline__ const u64 *pending_column(const IterState *st, const u64 *cols, u64 wp, const u64 *xbuf,
+                                                     u64 slot_words, u64 chunk_off)
+{
+    if (!st->prev_valid) return nullptr;
+    if (st->prev_local >= 0) return cols + (u64)st->prev_local * wp;
+    return xbuf + (u64)st->prev_rank * slot_words + UTM_HDR_WORDS + chunk_off;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: integer scores.  count[s] += popcount(col_s & ~covered) over one tile of the variant axis,
+// for one group of selectable samples (calculate_scores' row loop, select.py:37-41, as a bitset
+// reduction).  Grid = tiles x groups.  The workgroup stages ~covered for its tile in LDS once
+// (fusing the pending `covered |= winner` of the previous iteration, select.py:100), then each of
+// its 4 waves streams whole samples through that tile: one global_load_dwordx4 (1 KiB per wave)
+// + one ds_read_b128 + 4x(v_and, v_bcnt) per step, a wave reduction and ONE 64-bit atomic per
+// (sample, tile).  Integer adds: exact and order independent.
+// ------------------------------------------------------------------------------------------------
+template <int STEPS, bool NT>
+__global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+                                                   const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                                   const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                   u64 *__restrict__ cnt, unsigned group_size, unsigned n_groups)
+{
+    __shared__ v4u live[STEPS * 64];  // ~covered of this tile, STEPS KiB
+    if (st->done) return;
+    const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
+    const u64 left = (wp - w0) / UTM_STEP_WORDS;
+    const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
+
+    v4u *cv = reinterpret_cast<v4u *>(covered + w0);
+    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
+    for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
+        v4u c = cv[i];
+        if (wc) {
+            c |= wc[i];
+            // every group of this tile computes the same words; group 0 stores them.  A racing reader
+            // sees old or new words and ORs the winner in itself, so either is right.
+            if (grp == 0) cv[i] = c;
+        }
+        live[i] = ~c;
+    }
+    __syncthreads();
+
+    const unsigned n_active = st->n_active;
+    const unsigned lo = grp * group_size;
+    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int U = STEPS < 8 ? STEPS : 8;  // loads in flight per wave: U KiB
+    for (unsigned i = lo + wave; i < hi; i += 4) {
+        const unsigned s = act[i];
+        const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
+        unsigned acc = 0;
+        if (nsteps == STEPS) {
+#pragma unroll 1
+            for (int j0 = 0; j0 < STEPS; j0 += U) {
+                v4u x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    x[u] = NT ? __builtin_nontemporal_load(p + (j0 + u) * 64) : p[(j0 + u) * 64];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const v4u b = x[u] & live[(j0 + u) * 64 + lane];
+                    acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+                }
+            }
+        } else {
+            for (int j = 0; j < nsteps; ++j) {
+                const v4u b = p[j * 64] & live[j * 64 + lane];
+                acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+            }
+        }
+        acc = wave_sum_u32(acc);
+        if (lane == 0 && acc) atomicAdd(&cnt[s], (u64)acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1-AF (float32 AF as exact fixed point): besides the count, afsum[s] +=
+// sum of AFq[v] over the set, uncovered bits, AFq = AF * 2^q as int64.  Tile = 8192 variants: the
+// AFq tile (64 KiB) and ~covered (1 KiB) sit in LDS, a wave reads 1 KiB of one sample per step and
+// walks the surviving bits (ctz / clear-lowest / ds_read_b64 gather / 64-bit add).
+// ------------------------------------------------------------------------------------------------
+#define UTM_AF_TILE_WORDS 128
+__global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+                                                   const i64 *__restrict__ afq, const u64 *__restrict__ xbuf,
+                                                   u64 slot_words, u64 chunk_off, const IterState *__restrict__ st,
+                                                   const unsigned *__restrict__ act, u64 *__restrict__ cnt,
+                                                   i64 *__restrict__ afsum, unsigned group_size, unsigned n_groups)
+{
+    __shared__ i64 aq[UTM_AF_TILE_WORDS * 64];
+    __shared__ u64 live[UTM_AF_TILE_WORDS];
+    if (st->done) return;
+    const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    const u64 w0 = (u64)tile * UTM_AF_TILE_WORDS;
+    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    if (threadIdx.x < UTM_AF_TILE_WORDS) {
+        u64 c = covered[w0 + threadIdx.x];
+        if (wcol) {
+            c |= wcol[w0 + threadIdx.x];
+            if (grp == 0) covered[w0 + threadIdx.x] = c;
+        }
+        live[threadIdx.x] = ~c;
+    }
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(afq + w0 * 64);
+        int4 *dst = reinterpret_cast<int4 *>(aq);
+        for (int i = threadIdx.x; i < UTM_AF_TILE_WORDS * 32; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const unsigned n_active = st->n_active;
+    const unsigned lo = grp * group_size;
+    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u64 m0 = live[2 * lane], m1 = live[2 * lane + 1];
+    const i64 *a0 = aq + (2 * lane) * 64, *a1 = a0 + 64;
+    for (unsigned i = lo + wave; i < hi; i += 4) {
+        const unsigned s = act[i];
+        const ulonglong2 x = *(reinterpret_cast<const ulonglong2 *>(cols + (u64)s * wp + w0) + lane);
+        u64 b0 = x.x & m0, b1 = x.y & m1;
+        unsigned n = __popcll(b0) + __popcll(b1);
+        i64 sum = 0;
+        while (b0) { sum += a0[__builtin_ctzll(b0)]; b0 &= b0 - 1; }
+        while (b1) { sum += a1[__builtin_ctzll(b1)]; b1 &= b1 - 1; }
+        n = wave_sum_u32(n);
+        if (n) {  // wave uniform
+            sum = wave_sum_i64(sum);
+            if (lane == 0) {
+                atomicAdd(&cnt[s], (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), (u64)sum);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sequential AF (float64 AF, or float32 AF that fails the fixed-point precondition): the reference
+// adds row values into a float64 score in ascending variant order (`scores += row`, select.py:40);
+// float64 addition does not reassociate, so each sample's chain is walked by ONE lane, chunk after
+// chunk, word after word, bit after bit.  Latency bound by construction.
+// ------------------------------------------------------------------------------------------------
+struct SeqChunk {
+    const u64 *cols;
+    const u64 *covered;
+    const void *af;
+    u64 wp;
+    u64 w;  // words holding variants
+};
+template <typename AF_T>
+__global__ __launch_bounds__(64) void k_score_seq(const SeqChunk *__restrict__ chunks, int n_chunks,
+                                                  const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                  u64 *__restrict__ cnt, double *__restrict__ fscore)
+{
+    if (st->done) return;
+    const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= st->n_active) return;
+    const unsigned s = act[i];
+    double acc = 0.0;
+    u64 n = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const SeqChunk ch = chunks[c];
+        const ulonglong2 *col = reinterpret_cast<const ulonglong2 *>(ch.cols + (u64)s * ch.wp);
+        const ulonglong2 *cov = reinterpret_cast<const ulonglong2 *>(ch.covered);
+        const AF_T *af = static_cast<const AF_T *>(ch.af);
+        for (u64 w2 = 0; w2 < (ch.w + 1) / 2; ++w2) {  // wp is even, padding words are zero
+            const ulonglong2 x = col[w2];
+            const ulonglong2 m = cov[w2];
+            u64 b0 = x.x & ~m.x, b1 = x.y & ~m.y;
+            n += __popcll(b0) + __popcll(b1);
+            const AF_T *a = af + w2 * 128;
+            while (b0) { acc += (double)a[__builtin_ctzll(b0)]; b0 &= b0 - 1; }
+            a += 64;
+            while (b1) { acc += (double)a[__builtin_ctzll(b1)]; b1 &= b1 - 1; }
+        }
+    }
+    cnt[s] = n;
+    fscore[s] = acc;
+}
+
+// covered |= pending winner column (used where the update is not fused into a scoring kernel)
+__global__ __launch_bounds__(256) void k_apply_pending(u64 *__restrict__ covered, const u64 *__restrict__ cols, u64 wp,
+                                                       const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                                       const IterState *__restrict__ st)
+{
+    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    if (!wcol) return;
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) covered[w] |= wcol[w];
+}
+
+// covered |= cols[col]  (utm_reset: samples that start out "used")
+__global__ __launch_bounds__(256) void k_or_column(u64 *__restrict__ covered, const u64 *__restrict__ col, u64 wp)
+{
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) covered[w] |= col[w];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: mask / weight / argmax (select.py:43-53) over the selectable local samples and, when this is
+// the only shard, the decision and bookkeeping of greedy_select (select.py:93-112).  One workgroup.
+// ------------------------------------------------------------------------------------------------
+struct Cand {
+    double val;
+    i64 gidx;
+    i64 cnt;
+    unsigned pos;
+};
+__device__ __forceinline__ bool better(const Cand &a, const Cand &b)
+{  // np.argmax: highest score, first (lowest) index on ties
+    return a.val > b.val || (a.val == b.val && a.gidx < b.gidx);
+}
+__device__ __forceinline__ Cand shfl_cand(const Cand &c, int o)
+{
+    Cand r;
+    r.val = __shfl_xor(c.val, o, 64);
+    r.gidx = __shfl_xor(c.gidx, o, 64);
+    r.cnt = __shfl_xor(c.cnt, o, 64);
+    r.pos = __shfl_xor(c.pos, o, 64);
+    return r;
+}
+
+struct PickArgs {
+    IterState *st;
+    unsigned *act;
+    unsigned char *state;
+    const double *weights;  // n_samp_total, or nullptr
+    u64 *cnt;
+    i64 *afsum;      // fixed-point AF sums, or nullptr
+    double *fscore;  // sequential AF scores, or nullptr
+    double af_scale; // 2^-q
+    Rec *recs;       // exchange slot headers: recs[r] at xbuf + r*slot_words
+    u64 slot_words;
+    i64 *res_idx;
+    i64 *res_new;
+    double *res_score;
+    i64 n_var_total;
+    unsigned first, n_local, n_total;
+    int rank, n_ranks;
+};
+
+__device__ __forceinline__ Rec *rec_of(const PickArgs &a, int r)
+{
+    return reinterpret_cast<Rec *>(reinterpret_cast<u64 *>(a.recs) + (u64)r * a.slot_words);
+}
+
+// Runs in ONE thread.  Same inputs on every shard => same decision on every shard.
+__device__ void decide(const PickArgs &a)
+{
+    IterState *st = a.st;
+    Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+    int best_rank = -1;
+    for (int r = 0; r < a.n_ranks; ++r) {
+        const Rec *rc = rec_of(a, r);
+        if (rc->idx < 0) continue;
+        Cand c{rc->score, rc->idx, rc->new_count, 0};
+        if (best_rank < 0 || better(c, best)) { best = c; best_rank = r; }
+    }
+    const i64 k = st->iter;
+    // argmax runs over ALL samples in the reference; non-selectable ones hold 0 (select.py:43), so a
+    // negative best only wins when no such sample exists.
+    const bool zero_elsewhere = st->n_active_total < (i64)a.n_total;
+    if (best_rank < 0 || best.val == 0.0 || (best.val < 0.0 && zero_elsewhere)) {
+        st->done = 1;  // (None, None): no row for this iteration (select.py:51-52, :93-96)
+        a.res_idx[k] = -1;
+        return;
+    }
+    a.res_idx[k] = best.gidx;
+    a.res_new[k] = best.cnt;
+    a.res_score[k] = best.val;
+    st->iter = k + 1;
+    st->tot += best.cnt;
+    st->n_active_total -= 1;
+    st->prev_valid = 1;
+    st->prev_rank = best_rank;
+    if (best.gidx >= (i64)a.first && best.gidx < (i64)a.first + a.n_local) {
+        const unsigned loc = (unsigned)(best.gidx - a.first);
+        a.state[loc] = 0;  // sample_mask[use_sample] = 0 (select.py:100)
+        const unsigned n = st->n_active;
+        a.act[st->best_pos] = a.act[n - 1];
+        st->n_active = n - 1;
+        st->prev_local = (int)loc;
+    } else {
+        st->prev_local = -1;
+    }
+    if (st->tot >= a.n_var_total) st->done = 1;  // "Ran out of new variants" (select.py:110-112)
+}
+
+template <bool DECIDE>
+__global__ __launch_bounds__(256) void k_pick(PickArgs a)
+{
+    __shared__ Cand wbest[4];
+    IterState *st = a.st;
+    if (st->done) return;
+    const unsigned n_active = st->n_active;
+    Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+    for (unsigned i = threadIdx.x; i < n_active; i += 256) {
+        const unsigned s = a.act[i];
+        const u64 c = a.cnt[s];
+        a.cnt[s] = 0;  // ready for the next iteration's atomics
+        double v;
+        if (a.afsum) {
+            const i64 q = a.afsum[s];
+            a.afsum[s] = 0;
+            v = (double)q * a.af_scale;  // exact: |q| < 2^53 and the scale is a power of two
+        } else if (a.fscore) {
+            v = a.fscore[s];
+        } else {
+            v = (double)c;
+        }
+        if (a.weights) v *= a.weights[a.first + s];
+        const Cand cand{v, (i64)a.first + s, (i64)c, i};
+        if (better(cand, best)) best = cand;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const Cand other = shfl_cand(best, o);
+        if (better(other, best)) best = other;
+    }
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(wbest[w], best)) best = wbest[w];
+        Rec *rc = rec_of(a, a.rank);
+        rc->score = n_active ? best.val : 0.0;
+        rc->idx = n_active ? best.gidx : -1;
+        rc->new_count = n_active ? best.cnt : 0;
+        st->best_pos = best.pos;
+        if (DECIDE) decide(a);
+    }
+}
+
+__global__ void k_decide(PickArgs a)
+{
+    if (a.st->done) return;
+    if (threadIdx.x == 0) decide(a);
+}
+
+// Exchange payload: this shard's best column (all chunks back to back) behind its record.
+__global__ __launch_bounds__(256) void k_pack(u64 *__restrict__ slot_body, const u64 *__restrict__ cols, u64 wp,
+                                              const IterState *__restrict__ st, const unsigned *__restrict__ act)
+{
+    if (st->done || st->n_active == 0) return;
+    const u64 *col = cols + (u64)act[st->best_pos] * wp;
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) slot_body[w] = col[w];
+}
+
+// Final per-sample scores of the pending iteration (utm_peek_scores): mask, scale, weight.
+__global__ __launch_bounds__(256) void k_final_scores(PickArgs a, i64 *__restrict__ counts_out, double *__restrict__ scores_out)
+{
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_local) return;
+    const bool usable = a.state[s] == 1;
+    const u64 c = usable ? a.cnt[s] : 0;
+    double v = 0.0;
+    if (usable) v = a.afsum ? (double)a.afsum[s] * a.af_scale : a.fscore ? a.fscore[s] : (double)c;
+    if (a.weights) v *= a.weights[a.first + s];
+    counts_out[s] = (i64)c;
+    scores_out[s] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ingest helpers
+// ------------------------------------------------------------------------------------------------
+// Bit transpose of the reference's packing (rows = variants, MSB-first bits along samples,
+// convert.py:85) into columns.  One wave = 64 variants x 64 samples: lane l holds the 64 sample bits
+// of variant v0+l; 64 ballots turn them into 64 column words; lane j stores sample j's word.
+__global__ __launch_bounds__(64) void k_transpose_rows(const unsigned char *__restrict__ rows, u64 row_stride,
+                                                       u64 n_rows, u64 first_word, u64 *__restrict__ cols, u64 wp,
+                                                       unsigned first_sample, unsigned n_local, unsigned n_total)
+{
+    const u64 vw = blockIdx.x;     // word (64 variants) inside this upload
+    const unsigned sb = blockIdx.y;  // block of 64 local samples
+    const int lane = threadIdx.x;
+    const u64 v = vw * 64 + lane;
+    const unsigned sg0 = first_sample + sb * 64;  // first global sample of the block
+    u64 window = 0;  // bit (63 - j) = sample sg0 + j
+    if (v < n_rows) {
+        const unsigned char *row = rows + v * row_stride;
+        const unsigned byte0 = sg0 >> 3, sh = sg0 & 7;
+        const unsigned n_bytes = (n_total + 7) >> 3;
+        u64 hi = 0;
+        for (int b = 0; b < 8; ++b) hi = (hi << 8) | (byte0 + b < n_bytes ? row[byte0 + b] : 0);
+        const unsigned nxt = byte0 + 8 < n_bytes ? row[byte0 + 8] : 0;
+        window = sh ? (hi << sh) | (nxt >> (8 - sh)) : hi;
+    }
+    u64 mine = 0;
+    for (int j = 0; j < 64; ++j) {
+        const u64 word = __ballot((window >> (63 - j)) & 1);
+        if (lane == j) mine = word;
+    }
+    const unsigned s_local = sb * 64 + lane;
+    if (s_local < n_local && sg0 + lane < n_total) cols[(u64)s_local * wp + first_word + vw] = mine;
+}
+
+// cols[s][w] &= keep[w]   (variants whose AF is exactly 0 are all-zero rows in the reference's matrix)
+__global__ __launch_bounds__(256) void k_mask_rows(u64 *__restrict__ cols, u64 wp, const u64 *__restrict__ keep, u64 w_words,
+                                                   unsigned n_local)
+{
+    const u64 total = (u64)n_local * w_words;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += (u64)gridDim.x * 256) {
+        const u64 s = i / w_words, w = i % w_words;
+        cols[s * wp + w] &= keep[w];
+    }
+}
+
+// var_count: out[s] += popcount(column s)
+__global__ __launch_bounds__(256) void k_col_popcount(const u64 *__restrict__ cols, u64 wp, u64 *__restrict__ out)
+{
+    const unsigned s = blockIdx.x;
+    const u64 *col = cols + (u64)s * wp;
+    unsigned acc = 0;
+    u64 total = 0;
+    for (u64 w = threadIdx.x; w < wp; w += 256) {
+        acc += __popcll(col[w]);
+        if (acc > 0xF0000000u) { total += acc; acc = 0; }
+    }
+    total += acc;
+    __shared__ u64 part[4];
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) out[s] += part[0] + part[1] + part[2] + part[3];
+}
+
+// Synthetic chunk contents: thread = one word (64 variants) of one local sample.
+__global__ __launch_bounds__(256) void k_synth(u64 *__restrict__ cols, u64 wp, u64 n_var, u64 first_var_global,
+                                               u64 seed, unsigned n_total, unsigned first_sample, unsigned octaves,
+                                               u64 words_per_col)
+{
+    const u64 blocks_per_col = (words_per_col + 255) / 256;
+    const unsigned s = (unsigned)(blockIdx.x / blocks_per_col);
+    const u64 w = (blockIdx.x % blocks_per_col) * 256 + threadIdx.x;
+    if (w >= words_per_col) return;
+    const unsigned sg = first_sample + s;
+    const u64 skey = utm_sample_key(sg);
+    u64 word = 0;
+    for (int b = 0; b < 64; ++b) {
+        const u64 v = w * 64 + b;
+        if (v >= n_var) break;
+        const u64 key = utm_var_key(seed, first_var_global + v);
+        const unsigned thr = utm_var_threshold(key, octaves);
+        const unsigned forced = utm_var_forced(key, n_total);
+        word |= (u64)utm_cell(key, thr, forced, skey, sg) << b;
+    }
+    cols[(u64)s * wp + w] = word;
+}

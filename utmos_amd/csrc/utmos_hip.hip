@@ -1,0 +1,1030 @@
+// libutmos_hip.so -- host side of the C ABI declared in include/utmos_hip.h.
+//
+// Replaces the reference's hot path, utmos/select.py:24-53 (calculate_scores) and :69-112
+// (greedy_select), with a device-resident loop: per iteration one scoring launch per chunk (K1, fuses
+// the previous winner's `covered |= column`) and one single-workgroup pick (K2: mask, weights, argmax,
+// bookkeeping).  Nothing is read back until the loop ends or a 64-iteration batch boundary.
+#include "../../include/utmos_hip.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <rccl/rccl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "kernels.hip.h"
+
+// ---------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? UTM_ENOMEM : UTM_EHIP, "%s -> %s (%s:%d)", #expr,        \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                         \
+    } while (0)
+#define TRY(expr)                \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != UTM_OK) return rc_; \
+    } while (0)
+
+extern "C" const char *utm_last_error(void) { return g_err; }
+extern "C" int utm_abi_version(void) { return UTM_ABI_VERSION; }
+extern "C" int utm_device_count(int *n)
+{
+    if (!n) return fail(UTM_EINVAL, "n is NULL");
+    HIP_TRY(hipGetDeviceCount(n));
+    return UTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- RCCL (lazy)
+// librccl is loaded on first use so that single-GPU runs do not depend on it.
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+static int rccl_load()
+{
+    if (g_rccl.h) return UTM_OK;
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(UTM_ECOMM, "cannot load librccl.so: %s", dlerror());
+#define SYM(field, name)                                              \
+    *(void **)(&g_rccl.field) = dlsym(h, name);                        \
+    if (!g_rccl.field) return fail(UTM_ECOMM, "librccl.so lacks %s", name);
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(AllGather, "ncclAllGather")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    g_rccl.h = h;
+    return UTM_OK;
+}
+#define NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess)                                                                          \
+            return fail(UTM_ECOMM, "%s -> %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------- context
+struct Chunk {
+    u64 n_var = 0;
+    u64 w = 0;   // words holding variants
+    u64 wp = 0;  // words per column in memory (multiple of 128)
+    u64 off = 0; // word offset of this chunk inside a whole-column buffer
+    u64 *cols = nullptr;
+    u64 *covered = nullptr;
+    void *af = nullptr;   // device: float or double per variant (sequential modes)
+    i64 *afq = nullptr;   // device: fixed-point AF, wp*64 entries
+    std::vector<float> h_af32;
+    std::vector<double> h_af64;
+};
+
+struct utm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t flags = 0;
+    uint32_t n_total = 0, first = 0, n_local = 0;
+    std::vector<Chunk> chunks;
+    u64 n_var_total = 0;
+    u64 col_words = 0;  // sum of wp over chunks
+
+    unsigned char *d_state = nullptr;  // n_local
+    double *d_weights = nullptr;       // n_total or null
+    u64 *d_cnt = nullptr;              // n_local
+    i64 *d_afsum = nullptr;            // n_local
+    double *d_fscore = nullptr;        // n_local
+    unsigned *d_act = nullptr;         // n_local
+    IterState *d_st = nullptr;
+    IterState *h_st = nullptr;  // pinned
+    i64 *d_res_idx = nullptr, *d_res_new = nullptr;
+    double *d_res_score = nullptr;
+    u64 *d_xbuf = nullptr;  // n_ranks slots of slot_words
+    u64 slot_words = UTM_HDR_WORDS;
+    int xbuf_ranks = 0;
+    u64 xbuf_slot_words = UTM_HDR_WORDS;  // slot size the buffer was allocated for
+    SeqChunk *d_seq = nullptr;
+    u64 *d_varcount = nullptr;
+    bool varcount_valid = false;
+
+    std::vector<unsigned char> h_state;  // n_total, as last set (initial states)
+    bool have_weights = false;
+    int af_mode = UTM_AF_NONE;
+    bool af_fixed = false;
+    int af_q = 0;
+    bool prepared = false;  // device loop state matches h_state / AF tables
+    bool dirty_tables = true;
+
+    // host mirror of the loop
+    i64 iter = 0;             // rows produced
+    i64 scored = 0;           // scoring passes run (>= iter)
+    unsigned active_ub = 0;   // upper bound of local selectable samples (exact while the loop is alive)
+    bool finished = false;
+
+    // RCCL
+    int rank = 0, n_ranks = 1;
+    ncclComm_t comm = nullptr;
+
+    // stats
+    i64 score_launches = 0;
+    double loop_ms = 0.0;
+    i64 algo_bytes = 0;
+    std::vector<hipEvent_t> ev;  // pairs, UTM_FLAG_PROFILE_EVENTS
+    size_t ev_used = 0;
+    double score_ms = 0.0;
+    hipEvent_t ev_loop0 = nullptr, ev_loop1 = nullptr;
+};
+
+static inline u64 round_up(u64 x, u64 m) { return (x + m - 1) / m * m; }
+
+extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_sample, uint32_t n_samp_local,
+                              uint32_t flags, utm_ctx **out)
+{
+    if (!out) return fail(UTM_EINVAL, "out is NULL");
+    if (n_samp_total == 0 || n_samp_local == 0 || (u64)first_sample + n_samp_local > n_samp_total)
+        return fail(UTM_EINVAL, "bad sample range: total %u first %u local %u", n_samp_total, first_sample, n_samp_local);
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) return fail(UTM_EINVAL, "device %d not in [0,%d)", device, n_dev);
+    HIP_TRY(hipSetDevice(device));
+    utm_ctx *c = new utm_ctx();
+    c->device = device;
+    c->flags = flags;
+    c->n_total = n_samp_total;
+    c->first = first_sample;
+    c->n_local = n_samp_local;
+    c->h_state.assign(n_samp_total, 1);
+    *out = c;  // so that a failing allocation below can still be destroyed by the caller
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&c->d_state, n_samp_local));
+    HIP_TRY(hipMalloc(&c->d_cnt, (size_t)n_samp_local * 8));
+    HIP_TRY(hipMalloc(&c->d_afsum, (size_t)n_samp_local * 8));
+    HIP_TRY(hipMalloc(&c->d_fscore, (size_t)n_samp_local * 8));
+    HIP_TRY(hipMalloc(&c->d_act, (size_t)n_samp_local * 4));
+    HIP_TRY(hipMalloc(&c->d_varcount, (size_t)n_samp_local * 8));
+    HIP_TRY(hipMalloc(&c->d_st, sizeof(IterState)));
+    HIP_TRY(hipHostMalloc(&c->h_st, sizeof(IterState)));
+    HIP_TRY(hipMalloc(&c->d_res_idx, ((size_t)n_samp_total + 1) * 8));
+    HIP_TRY(hipMalloc(&c->d_res_new, ((size_t)n_samp_total + 1) * 8));
+    HIP_TRY(hipMalloc(&c->d_res_score, ((size_t)n_samp_total + 1) * 8));
+    HIP_TRY(hipMalloc(&c->d_xbuf, UTM_HDR_WORDS * 8));
+    c->xbuf_ranks = 1;
+    HIP_TRY(hipEventCreate(&c->ev_loop0));
+    HIP_TRY(hipEventCreate(&c->ev_loop1));
+    return UTM_OK;
+}
+
+extern "C" int utm_ctx_destroy(utm_ctx *c)
+{
+    if (!c) return UTM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (auto &ch : c->chunks) {
+        (void)hipFree(ch.cols);
+        (void)hipFree(ch.covered);
+        (void)hipFree(ch.af);
+        (void)hipFree(ch.afq);
+    }
+    (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
+    (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
+    (void)hipFree(c->d_xbuf); (void)hipFree(c->d_seq); (void)hipFree(c->d_varcount);
+    if (c->h_st) (void)hipHostFree(c->h_st);
+    for (auto e : c->ev) (void)hipEventDestroy(e);
+    if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
+    if (c->ev_loop1) (void)hipEventDestroy(c->ev_loop1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return UTM_OK;
+}
+
+#define CTX(c)                                        \
+    if (!(c)) return fail(UTM_EINVAL, "ctx is NULL"); \
+    HIP_TRY(hipSetDevice((c)->device))
+
+static int chunk_of(utm_ctx *c, int32_t chunk, Chunk **out)
+{
+    if (chunk < 0 || (size_t)chunk >= c->chunks.size()) return fail(UTM_EINVAL, "chunk %d not in [0,%zu)", chunk, c->chunks.size());
+    *out = &c->chunks[chunk];
+    return UTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- matrix
+extern "C" int utm_add_chunk(utm_ctx *c, uint64_t n_var, int32_t *chunk)
+{
+    CTX(c);
+    if (n_var == 0) return fail(UTM_EINVAL, "empty chunk");
+    if (c->comm) return fail(UTM_ESTATE, "chunks must be added before utm_comm_init");
+    Chunk ch;
+    ch.n_var = n_var;
+    ch.w = (n_var + 63) / 64;
+    ch.wp = round_up(ch.w, UTM_STEP_WORDS);
+    ch.off = c->col_words;
+    const size_t bytes = (size_t)c->n_local * ch.wp * 8;
+    HIP_TRY(hipMalloc(&ch.cols, bytes));
+    HIP_TRY(hipMemsetAsync(ch.cols, 0, bytes, c->stream));
+    HIP_TRY(hipMalloc(&ch.covered, ch.wp * 8));
+    HIP_TRY(hipMemsetAsync(ch.covered, 0, ch.wp * 8, c->stream));
+    c->chunks.push_back(std::move(ch));
+    c->n_var_total += n_var;
+    c->col_words += c->chunks.back().wp;
+    c->slot_words = UTM_HDR_WORDS + c->col_words;
+    c->prepared = false;
+    c->dirty_tables = true;
+    c->varcount_valid = false;
+    if (chunk) *chunk = (int32_t)c->chunks.size() - 1;
+    return UTM_OK;
+}
+
+extern "C" int utm_upload_columns(utm_ctx *c, int32_t chunk, uint32_t first_col, uint32_t n_cols,
+                                  const uint64_t *cols, uint64_t stride_words)
+{
+    CTX(c);
+    Chunk *ch;
+    TRY(chunk_of(c, chunk, &ch));
+    if (!cols || (u64)first_col + n_cols > c->n_local || stride_words < ch->w)
+        return fail(UTM_EINVAL, "bad column range/stride (first %u n %u stride %llu < %llu words)", first_col, n_cols,
+                    (u64)stride_words, ch->w);
+    HIP_TRY(hipMemcpy2DAsync(ch->cols + (u64)first_col * ch->wp, ch->wp * 8, cols, stride_words * 8, ch->w * 8, n_cols,
+                             hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->prepared = false;
+    c->varcount_valid = false;
+    return UTM_OK;
+}
+
+extern "C" int utm_download_columns(utm_ctx *c, int32_t chunk, uint32_t first_col, uint32_t n_cols, uint64_t *cols,
+                                    uint64_t stride_words)
+{
+    CTX(c);
+    Chunk *ch;
+    TRY(chunk_of(c, chunk, &ch));
+    if (!cols || (u64)first_col + n_cols > c->n_local || stride_words < ch->w)
+        return fail(UTM_EINVAL, "bad column range/stride");
+    HIP_TRY(hipMemcpy2DAsync(cols, stride_words * 8, ch->cols + (u64)first_col * ch->wp, ch->wp * 8, ch->w * 8, n_cols,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return UTM_OK;
+}
+
+extern "C" int utm_upload_rows_packed(utm_ctx *c, int32_t chunk, uint64_t first_var, uint64_t n_rows,
+                                      const uint8_t *rows, uint64_t row_stride_bytes)
+{
+    CTX(c);
+    Chunk *ch;
+    TRY(chunk_of(c, chunk, &ch));
+    if (!rows || n_rows == 0) return fail(UTM_EINVAL, "no rows");
+    if (first_var % 64 || first_var + n_rows > ch->n_var) return fail(UTM_EINVAL, "first_var must be a multiple of 64 and rows must fit the chunk");
+    if (row_stride_bytes < ((u64)c->n_total + 7) / 8) return fail(UTM_EINVAL, "row stride shorter than ceil(S/8)");
+    // staged in slabs of at most 64 MiB
+    const u64 slab_rows = std::max<u64>(64, ((64ull << 20) / row_stride_bytes) / 64 * 64);
+    unsigned char *d_rows = nullptr;
+    HIP_TRY(hipMalloc(&d_rows, std::min(slab_rows, round_up(n_rows, 64)) * row_stride_bytes));
+    int rc = UTM_OK;
+    for (u64 r0 = 0; r0 < n_rows && rc == UTM_OK; r0 += slab_rows) {
+        const u64 nr = std::min(slab_rows, n_rows - r0);
+        hipError_t e = hipMemcpyAsync(d_rows, rows + r0 * row_stride_bytes, nr * row_stride_bytes, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { rc = fail(UTM_EHIP, "row upload: %s", hipGetErrorString(e)); break; }
+        dim3 grid((unsigned)((nr + 63) / 64), (c->n_local + 63) / 64);
+        hipLaunchKernelGGL(k_transpose_rows, grid, dim3(64), 0, c->stream, d_rows, (u64)row_stride_bytes, nr,
+                           (first_var + r0) / 64, ch->cols, ch->wp, c->first, c->n_local, c->n_total);
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(UTM_EHIP, "row transpose: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_rows);
+    c->prepared = false;
+    c->varcount_valid = false;
+    return rc;
+}
+
+static int ensure_var_count(utm_ctx *c)
+{
+    if (c->varcount_valid) return UTM_OK;
+    HIP_TRY(hipMemsetAsync(c->d_varcount, 0, (size_t)c->n_local * 8, c->stream));
+    for (auto &ch : c->chunks)
+        hipLaunchKernelGGL(k_col_popcount, dim3(c->n_local), dim3(256), 0, c->stream, ch.cols, ch.wp, c->d_varcount);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->varcount_valid = true;
+    return UTM_OK;
+}
+
+extern "C" int utm_var_count(utm_ctx *c, int64_t *out)
+{
+    CTX(c);
+    if (!out) return fail(UTM_EINVAL, "out is NULL");
+    TRY(ensure_var_count(c));
+    HIP_TRY(hipMemcpy(out, c->d_varcount, (size_t)c->n_local * 8, hipMemcpyDeviceToHost));
+    return UTM_OK;
+}
+
+extern "C" int utm_synth_fill(utm_ctx *c, int32_t chunk, uint64_t seed, uint64_t first_var_global)
+{
+    CTX(c);
+    Chunk *ch;
+    TRY(chunk_of(c, chunk, &ch));
+    const u64 blocks_per_col = (ch->w + 255) / 256;
+    const u64 blocks = blocks_per_col * c->n_local;
+    if (blocks > 0x7FFFFFFFull) return fail(UTM_EINVAL, "chunk too large for one generator launch");
+    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, c->stream, ch->cols, ch->wp, ch->n_var,
+                       (u64)first_var_global, (u64)seed, c->n_total, c->first, utm_octaves(c->n_total), ch->w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->prepared = false;
+    c->varcount_valid = false;
+    return UTM_OK;
+}
+
+extern "C" int utm_synth_host(uint64_t seed, uint64_t first_var_global, uint64_t n_var, uint32_t n_samp_total,
+                              uint32_t first_sample, uint32_t n_samp, uint64_t *cols, uint64_t stride_words,
+                              float *af_out)
+{
+    const uint32_t oct = utm_octaves(n_samp_total);
+    const u64 w = (n_var + 63) / 64;
+    if (cols && stride_words < w) return fail(UTM_EINVAL, "stride shorter than ceil(n_var/64)");
+    std::vector<uint64_t> key(n_var);
+    std::vector<uint32_t> thr(n_var), forced(n_var);
+    for (u64 v = 0; v < n_var; ++v) {
+        key[v] = utm_var_key(seed, first_var_global + v);
+        thr[v] = utm_var_threshold(key[v], oct);
+        forced[v] = utm_var_forced(key[v], n_samp_total);
+        if (af_out) af_out[v] = utm_var_af(thr[v], n_samp_total);
+    }
+    if (cols)
+        for (uint32_t s = 0; s < n_samp; ++s) {
+            const uint32_t sg = first_sample + s;
+            const uint64_t skey = utm_sample_key(sg);
+            uint64_t *col = cols + (u64)s * stride_words;
+            for (u64 wi = 0; wi < w; ++wi) {
+                uint64_t word = 0;
+                for (int b = 0; b < 64; ++b) {
+                    const u64 v = wi * 64 + b;
+                    if (v >= n_var) break;
+                    word |= (uint64_t)utm_cell(key[v], thr[v], forced[v], skey, sg) << b;
+                }
+                col[wi] = word;
+            }
+        }
+    return UTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- options
+extern "C" int utm_set_sample_state(utm_ctx *c, const uint8_t *state)
+{
+    CTX(c);
+    if (!state) return fail(UTM_EINVAL, "state is NULL");
+    for (uint32_t s = 0; s < c->n_total; ++s)
+        if (state[s] > 2) return fail(UTM_EINVAL, "state[%u] = %u not in {0,1,2}", s, state[s]);
+    c->h_state.assign(state, state + c->n_total);
+    c->prepared = false;
+    return UTM_OK;
+}
+
+extern "C" int utm_set_weights(utm_ctx *c, const double *w)
+{
+    CTX(c);
+    if (!w) {
+        c->have_weights = false;
+        return UTM_OK;
+    }
+    for (uint32_t s = 0; s < c->n_total; ++s)
+        if (!isfinite(w[s])) return fail(UTM_EINVAL, "weights[%u] is not finite", s);
+    if (!c->d_weights) HIP_TRY(hipMalloc(&c->d_weights, (size_t)c->n_total * 8));
+    HIP_TRY(hipMemcpy(c->d_weights, w, (size_t)c->n_total * 8, hipMemcpyHostToDevice));
+    c->have_weights = true;
+    return UTM_OK;
+}
+
+extern "C" int utm_set_af(utm_ctx *c, int32_t chunk, int mode, const void *af)
+{
+    CTX(c);
+    if (mode == UTM_AF_NONE) {
+        if (af) return fail(UTM_EINVAL, "UTM_AF_NONE takes af == NULL");
+        for (auto &ch : c->chunks) { ch.h_af32.clear(); ch.h_af64.clear(); }
+        c->af_mode = UTM_AF_NONE;
+        c->dirty_tables = true;
+        c->prepared = false;
+        return UTM_OK;
+    }
+    Chunk *ch;
+    TRY(chunk_of(c, chunk, &ch));
+    if (mode != UTM_AF_F32 && mode != UTM_AF_F64) return fail(UTM_EINVAL, "mode %d", mode);
+    if (!af) return fail(UTM_EINVAL, "af is NULL");
+    if (c->af_mode != UTM_AF_NONE && c->af_mode != mode) {
+        for (auto &o : c->chunks)
+            if (&o != ch && (!o.h_af32.empty() || !o.h_af64.empty()))
+                return fail(UTM_ESTATE, "all chunks must use one AF mode");
+    }
+    // A variant whose AF is 0.0 is an all-zero row of the reference's float matrix (presence * AF):
+    // never counted, never scored, never covered.  var_count is taken from the boolean matrix
+    // (select.py:281-284), so it is latched before such rows are cleared.
+    std::vector<u64> keep(ch->w, ~0ull);
+    bool any_zero = false;
+    for (u64 v = 0; v < ch->n_var; ++v) {
+        const double a = mode == UTM_AF_F32 ? (double)((const float *)af)[v] : ((const double *)af)[v];
+        if (!isfinite(a) || a < 0) return fail(UTM_EINVAL, "AF[%llu] = %g must be finite and >= 0", v, a);
+        if (a == 0.0) { keep[v >> 6] &= ~(1ull << (v & 63)); any_zero = true; }
+    }
+    if (any_zero) {
+        TRY(ensure_var_count(c));
+        u64 *d_keep = nullptr;
+        HIP_TRY(hipMalloc(&d_keep, ch->w * 8));
+        HIP_TRY(hipMemcpy(d_keep, keep.data(), ch->w * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_mask_rows, dim3(4096), dim3(256), 0, c->stream, ch->cols, ch->wp, d_keep, ch->w, c->n_local);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_keep);
+        if (e != hipSuccess) return fail(UTM_EHIP, "mask rows: %s", hipGetErrorString(e));
+    }
+    ch->h_af32.clear();
+    ch->h_af64.clear();
+    if (mode == UTM_AF_F32) ch->h_af32.assign((const float *)af, (const float *)af + ch->n_var);
+    else ch->h_af64.assign((const double *)af, (const double *)af + ch->n_var);
+    c->af_mode = mode;
+    c->dirty_tables = true;
+    c->prepared = false;
+    return UTM_OK;
+}
+
+// Decide the AF arithmetic and build the device tables.
+static int build_af_tables(utm_ctx *c)
+{
+    if (!c->dirty_tables) return UTM_OK;
+    for (auto &ch : c->chunks) {
+        (void)hipFree(ch.af); ch.af = nullptr;
+        (void)hipFree(ch.afq); ch.afq = nullptr;
+    }
+    (void)hipFree(c->d_seq); c->d_seq = nullptr;
+    c->af_fixed = false;
+    c->af_q = 0;
+    if (c->af_mode == UTM_AF_NONE) { c->dirty_tables = false; return UTM_OK; }
+    for (auto &ch : c->chunks)
+        if ((c->af_mode == UTM_AF_F32 ? ch.h_af32.size() : ch.h_af64.size()) != ch.n_var)
+            return fail(UTM_ESTATE, "AF not set for every chunk");
+    if (c->af_mode == UTM_AF_F32 && !(c->flags & UTM_FLAG_AF_SEQUENTIAL)) {
+        // Every float32 a > 0 is m * 2^(e-23) with integer m < 2^24, i.e. a multiple of 2^-q for
+        // q = 23 - e_min.  If the total AF mass stays below 2^(53-q) every partial sum of the
+        // reference's float64 accumulation is exact, so the sum is order independent and equals
+        // (sum of a*2^q as int64) / 2^q bit for bit.
+        int e_min = 1000;
+        long double mass = 0;
+        for (auto &ch : c->chunks)
+            for (float a : ch.h_af32) {
+                if (a == 0.0f) continue;
+                int e;
+                frexpf(a, &e);  // a = f * 2^e, f in [0.5,1): exponent of the leading bit is e-1
+                const int lead = fpclassify(a) == FP_SUBNORMAL ? -126 : e - 1;
+                e_min = std::min(e_min, lead);
+                mass += a;
+            }
+        if (e_min == 1000) e_min = 0;
+        const int q = 23 - e_min;
+        if (q <= 60 && q >= 0 && mass < ldexpl(1.0L, 53 - q) * 0.999L) {
+            c->af_fixed = true;
+            c->af_q = q;
+        }
+    }
+    if (c->af_fixed) {
+        for (auto &ch : c->chunks) {
+            std::vector<i64> q(ch.wp * 64, 0);
+            for (u64 v = 0; v < ch.n_var; ++v) q[v] = (i64)ldexp((double)ch.h_af32[v], c->af_q);
+            HIP_TRY(hipMalloc(&ch.afq, q.size() * 8));
+            HIP_TRY(hipMemcpy(ch.afq, q.data(), q.size() * 8, hipMemcpyHostToDevice));
+        }
+    } else {
+        std::vector<SeqChunk> seq;
+        for (auto &ch : c->chunks) {
+            const size_t esz = c->af_mode == UTM_AF_F32 ? 4 : 8;
+            const size_t n = ch.wp * 64;
+            HIP_TRY(hipMalloc(&ch.af, n * esz));
+            HIP_TRY(hipMemset(ch.af, 0, n * esz));
+            HIP_TRY(hipMemcpy(ch.af, c->af_mode == UTM_AF_F32 ? (const void *)ch.h_af32.data() : (const void *)ch.h_af64.data(),
+                              ch.n_var * esz, hipMemcpyHostToDevice));
+            seq.push_back(SeqChunk{ch.cols, ch.covered, ch.af, ch.wp, ch.w});
+        }
+        HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
+        HIP_TRY(hipMemcpy(c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
+    }
+    c->dirty_tables = false;
+    return UTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- loop set-up
+static int ensure_xbuf(utm_ctx *c, int n_ranks)
+{
+    const u64 slot = (n_ranks == 1 && !c->comm) ? UTM_HDR_WORDS : c->slot_words;
+    if (c->d_xbuf && c->xbuf_ranks == n_ranks && c->xbuf_slot_words == slot) return UTM_OK;
+    (void)hipFree(c->d_xbuf);
+    c->d_xbuf = nullptr;
+    HIP_TRY(hipMalloc(&c->d_xbuf, (size_t)n_ranks * slot * 8));
+    HIP_TRY(hipMemset(c->d_xbuf, 0, (size_t)n_ranks * slot * 8));
+    c->xbuf_ranks = n_ranks;
+    c->xbuf_slot_words = slot;
+    return UTM_OK;
+}
+
+extern "C" int utm_reset(utm_ctx *c)
+{
+    CTX(c);
+    if (c->chunks.empty()) return fail(UTM_ESTATE, "no chunks");
+    TRY(build_af_tables(c));
+    TRY(ensure_xbuf(c, c->xbuf_ranks));
+    // local state + active list
+    std::vector<unsigned> act;
+    i64 active_total = 0;
+    for (uint32_t s = 0; s < c->n_total; ++s) active_total += c->h_state[s] == 1;
+    for (uint32_t s = 0; s < c->n_local; ++s)
+        if (c->h_state[c->first + s] == 1) act.push_back(s);
+    HIP_TRY(hipMemcpyAsync(c->d_state, c->h_state.data() + c->first, c->n_local, hipMemcpyHostToDevice, c->stream));
+    if (!act.empty()) HIP_TRY(hipMemcpyAsync(c->d_act, act.data(), act.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_fscore, 0, (size_t)c->n_local * 8, c->stream));
+    for (auto &ch : c->chunks) {
+        HIP_TRY(hipMemsetAsync(ch.covered, 0, ch.wp * 8, c->stream));
+        // samples that start out used cover their variants from the first iteration (select.py:36-39)
+        for (uint32_t s = 0; s < c->n_local; ++s)
+            if (c->h_state[c->first + s] == 0)
+                hipLaunchKernelGGL(k_or_column, dim3(256), dim3(256), 0, c->stream, ch.covered, ch.cols + (u64)s * ch.wp, ch.wp);
+    }
+    HIP_TRY(hipGetLastError());
+    IterState st;
+    memset(&st, 0, sizeof st);
+    st.n_active = (unsigned)act.size();
+    st.n_active_total = active_total;
+    st.prev_local = -1;
+    HIP_TRY(hipMemcpyAsync(c->d_st, &st, sizeof st, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->iter = 0;
+    c->scored = 0;
+    c->active_ub = (unsigned)act.size();
+    c->finished = false;
+    c->score_launches = 0;
+    c->score_ms = 0;
+    c->algo_bytes = 0;
+    c->ev_used = 0;
+    c->prepared = true;
+    return UTM_OK;
+}
+
+static int ensure_prepared(utm_ctx *c)
+{
+    if (c->prepared && !c->dirty_tables) return UTM_OK;
+    return utm_reset(c);
+}
+
+static PickArgs pick_args(utm_ctx *c)
+{
+    PickArgs a;
+    a.st = c->d_st;
+    a.act = c->d_act;
+    a.state = c->d_state;
+    a.weights = c->have_weights ? c->d_weights : nullptr;
+    a.cnt = c->d_cnt;
+    a.afsum = (c->af_mode != UTM_AF_NONE && c->af_fixed) ? c->d_afsum : nullptr;
+    a.fscore = (c->af_mode != UTM_AF_NONE && !c->af_fixed) ? c->d_fscore : nullptr;
+    a.af_scale = ldexp(1.0, -c->af_q);
+    a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
+    a.slot_words = c->xbuf_slot_words;
+    a.res_idx = c->d_res_idx;
+    a.res_new = c->d_res_new;
+    a.res_score = c->d_res_score;
+    a.n_var_total = (i64)c->n_var_total;
+    a.first = c->first;
+    a.n_local = c->n_local;
+    a.n_total = c->n_total;
+    a.rank = c->rank;
+    a.n_ranks = c->xbuf_ranks;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------- launches
+static int tune_env(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+template <int STEPS>
+static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups, bool nt)
+{
+    const u64 slot = c->xbuf_slot_words;
+    if (nt)
+        hipLaunchKernelGGL((k_score_int<STEPS, true>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
+                           c->d_xbuf, slot, ch.off, c->d_st, c->d_act, c->d_cnt, group, n_groups);
+    else
+        hipLaunchKernelGGL((k_score_int<STEPS, false>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
+                           c->d_xbuf, slot, ch.off, c->d_st, c->d_act, c->d_cnt, group, n_groups);
+}
+
+// Enqueue the scoring of one iteration for every chunk (and the pending covered update).
+static int enqueue_score(utm_ctx *c)
+{
+    const unsigned a_ub = std::max(1u, c->active_ub);
+    const u64 slot = c->xbuf_slot_words;
+    static const int target_wgs = tune_env("UTM_TARGET_WGS", 4096);
+    static const int min_wgs = tune_env("UTM_MIN_WGS", 1024);
+    static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
+    static const int use_nt = tune_env("UTM_NT_LOADS", 1);
+    const bool profile = c->flags & UTM_FLAG_PROFILE_EVENTS;
+    auto ev_begin = [&]() {
+        if (!profile) return;
+        if (c->ev_used + 2 > c->ev.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            c->ev.push_back(a); c->ev.push_back(b);
+        }
+        (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+    };
+    auto ev_end = [&]() {
+        if (!profile) return;
+        (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
+        c->ev_used += 2;
+    };
+    if (c->af_mode != UTM_AF_NONE && !c->af_fixed) {
+        // sequential chain: update covered first, then one lane per sample over all chunks
+        for (auto &ch : c->chunks)
+            hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                               ch.covered, ch.cols, ch.wp, c->d_xbuf, slot, ch.off, c->d_st);
+        ev_begin();
+        const unsigned blocks = (a_ub + 63) / 64;
+        if (c->af_mode == UTM_AF_F32)
+            hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                               c->d_act, c->d_cnt, c->d_fscore);
+        else
+            hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                               c->d_act, c->d_cnt, c->d_fscore);
+        ev_end();
+        c->score_launches += 1;
+    } else {
+        for (auto &ch : c->chunks) {
+            ev_begin();
+            if (c->af_mode != UTM_AF_NONE) {
+                const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
+                // few, large groups: every workgroup re-stages its 64 KiB AF tile
+                unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)target_wgs / std::max<u64>(1, tiles)));
+                unsigned group = ((a_ub + n_groups - 1) / n_groups + 3) / 4 * 4;
+                n_groups = (a_ub + group - 1) / group;
+                hipLaunchKernelGGL(k_score_afq, dim3((unsigned)(tiles * n_groups)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
+                                   ch.afq, c->d_xbuf, slot, ch.off, c->d_st, c->d_act, c->d_cnt, c->d_afsum, group, n_groups);
+            } else {
+                const u64 steps_total = ch.wp / UTM_STEP_WORDS;
+                const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
+                int steps = 2;
+                for (int cand : {32, 8}) {
+                    const u64 tiles = (steps_total + cand - 1) / cand;
+                    if (tiles * waves_needed >= (u64)min_wgs) { steps = cand; break; }
+                }
+                if (force_steps == 32 || force_steps == 8 || force_steps == 2) steps = force_steps;
+                const u64 tiles = (steps_total + steps - 1) / steps;
+                u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
+                group = std::max<u64>(4, (group + 3) / 4 * 4);
+                const unsigned n_groups = (unsigned)((a_ub + group - 1) / group);
+                const unsigned blocks = (unsigned)(tiles * n_groups);
+                if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+                else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+                else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+            }
+            ev_end();
+            c->score_launches += 1;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return UTM_OK;
+}
+
+// Algorithmic HBM bytes of one iteration with `a` selectable local samples:
+// active columns + covered read + winner column re-read + covered write (+ AF values).
+static i64 iteration_bytes(const utm_ctx *c, u64 a)
+{
+    i64 b = 0;
+    for (auto &ch : c->chunks) {
+        b += (i64)((a + 3) * ch.w * 8);
+        if (c->af_mode == UTM_AF_F32) b += (i64)ch.n_var * 4;
+        if (c->af_mode == UTM_AF_F64) b += (i64)ch.n_var * 8;
+    }
+    return b;
+}
+
+static int enqueue_pick_and_exchange(utm_ctx *c)
+{
+    PickArgs a = pick_args(c);
+    if (!c->comm) {
+        hipLaunchKernelGGL(k_pick<true>, dim3(1), dim3(256), 0, c->stream, a);
+    } else {
+        hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(256), 0, c->stream, a);
+        u64 *slot = c->d_xbuf + (u64)c->rank * c->xbuf_slot_words;
+        for (auto &ch : c->chunks)
+            hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                               slot + UTM_HDR_WORDS + ch.off, ch.cols, ch.wp, c->d_st, c->d_act);
+        HIP_TRY(hipGetLastError());
+        // one exchange per iteration: every shard's {record, candidate column}, in place
+        NCCL_TRY(g_rccl.AllGather(slot, c->d_xbuf, c->xbuf_slot_words, ncclUint64, c->comm, c->stream));
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return UTM_OK;
+}
+
+// Bring the host mirror up to date with the device after a sync.
+static int sync_state(utm_ctx *c)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->iter = c->h_st->iter;
+    c->active_ub = c->h_st->n_active;
+    c->finished = c->h_st->done != 0;
+    return UTM_OK;
+}
+
+static int collect_event_times(utm_ctx *c)
+{
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        c->score_ms += ms;
+    }
+    c->ev_used = 0;
+    return UTM_OK;
+}
+
+extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new_out, double *score_out,
+                       int64_t *n_done)
+{
+    CTX(c);
+    if (k_max < 0 || !n_done || (k_max > 0 && (!idx_out || !new_out))) return fail(UTM_EINVAL, "bad outputs");
+    TRY(ensure_prepared(c));
+    *n_done = 0;
+    const i64 iter0 = c->iter;
+    const i64 room = (i64)c->n_total - iter0;
+    if (k_max > room) k_max = room;
+    HIP_TRY(hipEventRecord(c->ev_loop0, c->stream));
+    static const int batch = std::max(1, tune_env("UTM_BATCH", 64));
+    i64 enq = 0;
+    while (enq < k_max && !c->finished) {
+        const i64 n = std::min<i64>(batch, k_max - enq);
+        const unsigned a0 = c->active_ub;
+        for (i64 j = 0; j < n; ++j) {
+            TRY(enqueue_score(c));
+            TRY(enqueue_pick_and_exchange(c));
+            if (c->n_ranks == 1 && c->active_ub > 0) c->active_ub -= 1;  // exact while the loop is alive
+        }
+        enq += n;
+        const i64 before = c->iter;
+        TRY(sync_state(c));
+        // bytes: iterations that were actually scored in this batch (rows + a terminating empty pass)
+        const i64 rows = c->iter - before;
+        const i64 passes = std::min<i64>(n, rows + ((c->finished && c->h_st->tot < (i64)c->n_var_total && rows < n) ? 1 : 0));
+        for (i64 j = 0; j < passes; ++j)
+            c->algo_bytes += iteration_bytes(c, c->n_ranks == 1 ? (a0 > (u64)j ? a0 - j : 0) : a0);
+        c->scored += passes;
+        if (c->flags & UTM_FLAG_PROFILE_EVENTS) TRY(collect_event_times(c));
+    }
+    HIP_TRY(hipEventRecord(c->ev_loop1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_loop1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_loop0, c->ev_loop1));
+    c->loop_ms = ms;
+    const i64 rows = c->iter - iter0;
+    if (rows > 0) {
+        HIP_TRY(hipMemcpy(idx_out, c->d_res_idx + iter0, rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(new_out, c->d_res_new + iter0, rows * 8, hipMemcpyDeviceToHost));
+        if (score_out) HIP_TRY(hipMemcpy(score_out, c->d_res_score + iter0, rows * 8, hipMemcpyDeviceToHost));
+    }
+    *n_done = rows;
+    return UTM_OK;
+}
+
+extern "C" int utm_step(utm_ctx *c, int64_t *idx, int64_t *new_count, double *score)
+{
+    int64_t i = -1, n = 0, done = 0;
+    double s = 0;
+    CTX(c);
+    TRY(ensure_prepared(c));
+    if (!c->finished && c->iter < (i64)c->n_total) TRY(utm_run(c, 1, &i, &n, &s, &done));
+    if (done == 0) { i = -1; n = 0; s = 0; }
+    if (idx) *idx = i;
+    if (new_count) *new_count = n;
+    if (score) *score = s;
+    return UTM_OK;
+}
+
+extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
+{
+    CTX(c);
+    TRY(ensure_prepared(c));
+    TRY(enqueue_score(c));
+    i64 *d_counts = nullptr;
+    double *d_scores = nullptr;
+    HIP_TRY(hipMalloc(&d_counts, (size_t)c->n_local * 8));
+    HIP_TRY(hipMalloc(&d_scores, (size_t)c->n_local * 8));
+    hipLaunchKernelGGL(k_final_scores, dim3((c->n_local + 255) / 256), dim3(256), 0, c->stream, pick_args(c), d_counts, d_scores);
+    (void)hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream);
+    (void)hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && counts) e = hipMemcpy(counts, d_counts, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && scores) e = hipMemcpy(scores, d_scores, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_scores);
+    if (e != hipSuccess) return fail(UTM_EHIP, "peek: %s", hipGetErrorString(e));
+    return UTM_OK;
+}
+
+static int flush_pending(utm_ctx *c)
+{
+    const u64 slot = c->xbuf_slot_words;
+    for (auto &ch : c->chunks)
+        hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                           ch.covered, ch.cols, ch.wp, c->d_xbuf, slot, ch.off, c->d_st);
+    HIP_TRY(hipGetLastError());
+    return UTM_OK;
+}
+
+extern "C" int utm_get_covered(utm_ctx *c, int32_t chunk, uint64_t *out)
+{
+    CTX(c);
+    Chunk *ch;
+    TRY(chunk_of(c, chunk, &ch));
+    if (!out) return fail(UTM_EINVAL, "out is NULL");
+    TRY(ensure_prepared(c));
+    TRY(flush_pending(c));
+    HIP_TRY(hipMemcpyAsync(out, ch->covered, ch->w * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return UTM_OK;
+}
+
+extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
+{
+    CTX(c);
+    if (!out) return fail(UTM_EINVAL, "out is NULL");
+    memset(out, 0, sizeof *out);
+    out->iterations = c->iter;
+    out->tot_captured = c->prepared ? c->h_st->tot : 0;
+    out->score_launches = c->score_launches;
+    out->score_ms = c->score_ms;
+    out->loop_ms = c->loop_ms;
+    out->algo_bytes = c->algo_bytes;
+    out->af_mode = c->af_mode;
+    out->af_fixed_point = c->af_fixed;
+    out->af_q = c->af_q;
+    out->n_chunks = (int32_t)c->chunks.size();
+    return UTM_OK;
+}
+
+extern "C" int utm_set_profile(utm_ctx *c, int32_t on)
+{
+    CTX(c);
+    if (on) c->flags |= UTM_FLAG_PROFILE_EVENTS;
+    else c->flags &= ~UTM_FLAG_PROFILE_EVENTS;
+    return UTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- sharded building blocks
+extern "C" int utm_column_words(utm_ctx *c, uint64_t *n_words)
+{
+    CTX(c);
+    if (!n_words) return fail(UTM_EINVAL, "n_words is NULL");
+    *n_words = c->col_words;
+    return UTM_OK;
+}
+
+extern "C" int utm_local_best(utm_ctx *c, utm_record *rec)
+{
+    CTX(c);
+    if (!rec) return fail(UTM_EINVAL, "rec is NULL");
+    TRY(ensure_prepared(c));
+    memset(rec, 0, sizeof *rec);
+    rec->idx = -1;
+    if (c->finished) return UTM_OK;
+    TRY(enqueue_score(c));
+    PickArgs a = pick_args(c);
+    hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(256), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    const u64 slot = c->xbuf_slot_words;
+    HIP_TRY(hipMemcpyAsync(rec, c->d_xbuf + (u64)c->rank * slot, sizeof *rec, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->algo_bytes += iteration_bytes(c, c->active_ub);
+    c->scored += 1;
+    return UTM_OK;
+}
+
+extern "C" int utm_get_column(utm_ctx *c, int64_t global_idx, uint64_t *out)
+{
+    CTX(c);
+    if (!out || global_idx < (i64)c->first || global_idx >= (i64)c->first + c->n_local)
+        return fail(UTM_EINVAL, "sample %lld is not local", (long long)global_idx);
+    const u64 s = (u64)(global_idx - c->first);
+    for (auto &ch : c->chunks)
+        HIP_TRY(hipMemcpyAsync(out + ch.off, ch.cols + s * ch.wp, ch.wp * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return UTM_OK;
+}
+
+extern "C" int utm_apply_records(utm_ctx *c, const utm_record *recs, int32_t n_ranks, const uint64_t *winner_col,
+                                 int64_t *idx, int64_t *new_count, double *score)
+{
+    CTX(c);
+    if (!recs || n_ranks < 1) return fail(UTM_EINVAL, "bad records");
+    if (c->comm) return fail(UTM_ESTATE, "context exchanges through RCCL; use utm_step/utm_run");
+    TRY(ensure_prepared(c));
+    TRY(ensure_xbuf(c, n_ranks));
+    const u64 slot = c->xbuf_slot_words;
+    // who wins (same rule as decide()) -- only needed to place the winner's column in its slot
+    int win = -1;
+    for (int r = 0; r < n_ranks; ++r) {
+        if (recs[r].idx < 0) continue;
+        if (win < 0 || recs[r].score > recs[win].score || (recs[r].score == recs[win].score && recs[r].idx < recs[win].idx)) win = r;
+    }
+    for (int r = 0; r < n_ranks; ++r)
+        HIP_TRY(hipMemcpyAsync(c->d_xbuf + (u64)r * slot, &recs[r], sizeof(utm_record), hipMemcpyHostToDevice, c->stream));
+    if (win >= 0 && winner_col) {
+        if (n_ranks == 1) return fail(UTM_EINVAL, "winner_col given for a single shard");
+        HIP_TRY(hipMemcpyAsync(c->d_xbuf + (u64)win * slot + UTM_HDR_WORDS, winner_col, c->col_words * 8, hipMemcpyHostToDevice, c->stream));
+    } else if (win >= 0) {
+        const i64 g = recs[win].idx;
+        if (g < (i64)c->first || g >= (i64)c->first + c->n_local) return fail(UTM_EINVAL, "winner %lld is remote but winner_col is NULL", (long long)g);
+    }
+    const i64 before = c->iter;
+    hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, pick_args(c));
+    HIP_TRY(hipGetLastError());
+    TRY(sync_state(c));
+    int64_t i = -1, n = 0;
+    double s = 0;
+    if (c->iter > before) {
+        HIP_TRY(hipMemcpy(&i, c->d_res_idx + before, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&n, c->d_res_new + before, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&s, c->d_res_score + before, 8, hipMemcpyDeviceToHost));
+    }
+    if (idx) *idx = i;
+    if (new_count) *new_count = n;
+    if (score) *score = s;
+    return UTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- RCCL
+extern "C" int utm_comm_get_unique_id(void *id)
+{
+    if (!id) return fail(UTM_EINVAL, "id is NULL");
+    TRY(rccl_load());
+    static_assert(sizeof(ncclUniqueId) == UTM_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return UTM_OK;
+}
+
+extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const void *id)
+{
+    CTX(c);
+    if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(UTM_EINVAL, "bad rank %d of %d", rank, n_ranks);
+    if (c->comm) return fail(UTM_ESTATE, "communicator already initialised");
+    if (c->chunks.empty()) return fail(UTM_ESTATE, "add the chunks before utm_comm_init (the exchange buffer is sized from them)");
+    TRY(rccl_load());
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    NCCL_TRY(g_rccl.CommInitRank(&c->comm, n_ranks, u, rank));
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    TRY(ensure_xbuf(c, n_ranks));  // c->comm is set: slots carry whole columns
+    c->prepared = false;
+    return UTM_OK;
+}
+
+extern "C" int utm_comm_allreduce_max(utm_ctx *c, double *value)
+{
+    CTX(c);
+    if (!value) return fail(UTM_EINVAL, "value is NULL");
+    if (!c->comm) return UTM_OK;  // single shard: identity
+    double *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 8));
+    HIP_TRY(hipMemcpyAsync(d, value, 8, hipMemcpyHostToDevice, c->stream));
+    ncclResult_t r = g_rccl.AllReduce(d, d, 1, ncclDouble, ncclMax, c->comm, c->stream);
+    hipError_t e = hipMemcpyAsync(value, d, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (r != ncclSuccess) return fail(UTM_ECOMM, "ncclAllReduce -> %s", g_rccl.GetErrorString(r));
+    if (e != hipSuccess) return fail(UTM_EHIP, "allreduce copy: %s", hipGetErrorString(e));
+    return UTM_OK;
+}
