@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--af", action="store_true", help="configs[2]: float32 AF weighting")
     p.add_argument("--chunk-vars", type=int, default=0, help="split the variant axis into chunks of this many variants")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-vars", type=int, default=300_000)
+    p.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
     p.add_argument("--no-roofline-pass", action="store_true")
     return p.parse_args()
 
