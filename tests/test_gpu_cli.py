@@ -1,0 +1,105 @@
+"""`utmos select` end to end on the GPU: every golden TSV of the reference's suite, byte for byte,
+through the CLI (repo_utils/utmos_ssshtests.sh:81-235 with .npz re-encodings of the same inputs)."""
+import os
+
+import pytest
+
+import oracle_util as ou
+
+pytestmark = pytest.mark.gpu
+CASES = ou.golden_cases()
+
+
+def run_cli(argv):
+    from utmos_amd.select import select_main
+    select_main(argv)
+
+
+def cli_args(case, tmp_path, extra=()):
+    argv = []
+    skip = False
+    for a in case["args"]:
+        if skip:
+            skip = False
+            continue
+        if a == "--af-dtype":        # expressed through --lowmem in the CLI, like the reference's hdf5 path
+            skip = True
+            continue
+        if a in ("weights.txt", "subset.txt", "exclude.txt"):
+            a = os.path.join(ou.GOLD, a)
+        argv.append(a)
+    out = str(tmp_path / "out.txt")
+    inputs = [os.path.join(ou.GOLD, n + ".npz") for n in case["inputs"]]
+    return argv + list(extra) + ["-o", out] + inputs, out
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if n != "select_af_h5"))
+def test_cli_reproduces_golden(name, tmp_path):
+    argv, out = cli_args(CASES[name], tmp_path)
+    run_cli(argv)
+    assert open(out).read() == ou.golden_text(CASES[name])
+
+
+@pytest.mark.parametrize("name", ["select_first", "select_multi", "select_af", "select_weightsaf"])
+def test_cli_forced_chunking_is_result_neutral(name, tmp_path):
+    # --maxmem 0 is the reference's hook for its chunked/hdf5 branch (select.py:18-19); here it forces
+    # many small HBM chunks
+    argv, out = cli_args(CASES[name], tmp_path, extra=["--maxmem", "0", "--buffer", "256"])
+    run_cli(argv)
+    assert open(out).read() == ou.golden_text(CASES[name])
+
+
+def test_cli_lowmem_store_create_and_reuse(tmp_path):
+    # utmos_ssshtests.sh:197-216: create the store, then reuse it via --lowmem and as the only input
+    store = str(tmp_path / "tiny.utm")
+    argv, out = cli_args(CASES["select_first"], tmp_path, extra=["--maxmem", "0", "--lowmem", store])
+    run_cli(argv)
+    assert open(out).read() == ou.golden_text(CASES["select_first"])
+    for reuse in (["--lowmem", store], [store]):
+        out2 = str(tmp_path / "reuse.txt")
+        run_cli(["--maxmem", "1", "-o", out2] + reuse)
+        assert open(out2).read() == ou.golden_text(CASES["select_first"])
+
+
+def test_cli_lowmem_af_uses_float32_values(tmp_path):
+    # utmos_ssshtests.sh:218-235: the hdf5 path stores presence*AF as float32 and ranks differently
+    store = str(tmp_path / "tiny.af.utm")
+    case = CASES["select_af_h5"]
+    argv, out = cli_args(case, tmp_path, extra=["--maxmem", "0", "--lowmem", store])
+    run_cli(argv)
+    assert open(out).read() == ou.golden_text(case)
+    out2 = str(tmp_path / "reuse.txt")
+    run_cli(["--maxmem", "1", "-c", "20", "--lowmem", store, "-o", out2])          # :225 (no --af: logs, still AF scores)
+    assert open(out2).read() == ou.golden_text(case)
+    run_cli(["--af", "--maxmem", "1", "-c", "20", store, "-o", out2])               # :231
+    assert open(out2).read() == ou.golden_text(case)
+
+
+def test_cli_af_on_store_without_af_exits_1(tmp_path):
+    store = str(tmp_path / "plain.utm")
+    argv, _ = cli_args(CASES["select_intcnt"], tmp_path, extra=["--lowmem", store])
+    run_cli(argv)
+    with pytest.raises(SystemExit) as e:
+        run_cli(["--af", store])
+    assert e.value.code == 1
+
+
+def test_calculate_scores_drop_in(tmp_path):
+    import numpy as np
+    from utmos_amd import device
+    from utmos_amd.select import calculate_scores
+    rng = np.random.default_rng(3)
+    dense = ou.random_dense(rng, 4000, 37)
+    cols = ou.npo.pack_columns(dense)
+    mask = np.ones(37, np.uint8)
+    mask[[2, 9]] = 0
+    mask[5] = 2
+    w = rng.choice([1.0, 2.0], 37)
+    with device.DeviceMatrix(37) as m:
+        c = m.add_chunk(4000)
+        m.upload_columns(c, cols)
+        use, new = calculate_scores(m, mask, w)
+        e_use, e_new = ou.npo.score_rowloop(dense, mask, w)
+        assert (use, new) == (e_use, e_new)
+        mask[:] = 0
+        assert calculate_scores(m, mask) == (None, None)

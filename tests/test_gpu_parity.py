@@ -268,3 +268,47 @@ def test_rccl_single_rank_path(dev):
         assert m.allreduce_max(3.5) == 3.5
         got = m.run(n_samp)
     assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+
+
+def _gpu_shard_worker(rank, world, port, q):
+    # no torch in a process that runs libutmos_hip.so: its wheel carries another HIP runtime
+    from utmos_amd.sharded import SocketTransport
+    transport = SocketTransport(rank, world, port=port)
+    try:
+        from utmos_amd import device
+        from utmos_amd.sharded import shard_bounds, sharded_greedy
+        n_var, n_samp = 40_000, 96
+        cols, af = device.synth_host(5, n_var, n_samp)
+        state = np.ones(n_samp, np.uint8)
+        state[11] = 2
+        first, n_local = shard_bounds(n_samp, rank, world)
+        with device.DeviceMatrix(n_samp, device=0, first_sample=first, n_local=n_local) as m:
+            c = m.add_chunk(n_var)
+            m.synth_fill(c, seed=5)              # every rank generates its own columns of the same matrix
+            m.set_af(c, af)
+            m.set_state(state)
+            m.reset()
+            got = list(sharded_greedy(m, transport, n_samp))
+        exp = ou.c_greedy(cols, n_var, state, af=af)
+        ok = [g[0] for g in got] == exp[0].tolist() and [g[2] for g in got] == exp[2].tolist()
+        q.put((rank, ok, len(got)))
+    finally:
+        transport.close()
+
+
+def test_two_processes_share_the_gpu_host_staged_exchange(dev):
+    """One process per shard (as on a multi-GPU node), here both on the single GPU of the box:
+    HIP kernels for the local scoring, TCP sockets for the exchange (the gloo variant of the same
+    protocol runs on CPU in tests/test_host_logic.py)."""
+    import multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gpu_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res) and res[0][2] == res[1][2] > 50

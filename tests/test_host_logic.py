@@ -1,0 +1,153 @@
+"""Host-side logic without a GPU: argument handling, option parsing, the greedy driver's bookkeeping
+(with an oracle-backed stand-in for the device matrix) and the sharded protocol over gloo."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from fake_shard import FakeShard
+from oracle_util import npo
+
+
+def test_parse_helpers(golden_dir):
+    from utmos_amd.select import parse_sample_lists, parse_weights
+    assert parse_weights(os.path.join(golden_dir, "weights.txt")) == {"HG00280": 4.0, "NA20320": 10.0}
+    assert parse_weights(None) is None
+    assert parse_sample_lists(None) == []
+    assert parse_sample_lists(["A,B", os.path.join(golden_dir, "exclude.txt")]) == ["A", "B", "HG02332", "HG03097"]
+    assert len(parse_sample_lists([os.path.join(golden_dir, "subset.txt")])) == 126
+
+
+@pytest.mark.parametrize("argv", [["doesntexist.txt"], ["multi.utm", "multi.utm"], [], ["old.hdf5"]])
+def test_bad_inputs_exit_1(argv):
+    # utmos_ssshtests.sh:178-191: bad file, store + several inputs, no input -> exit code 1
+    from utmos_amd.select import select_main
+    with pytest.raises(SystemExit) as e:
+        select_main(argv)
+    assert e.value.code == 1
+
+
+def test_store_input_switches_lowmem_on():
+    from utmos_amd.select import parse_args
+    a = parse_args(["x.utm"])
+    assert a.lowmem == 1 and a.in_files == ["x.utm"]
+    a = parse_args(["--lowmem", "y.utm"])
+    assert a.lowmem == 1 and a.in_files == ["y.utm"]
+    a = parse_args(["--lowmem", "y.utm", "a.npz", "-c", "-1"])
+    assert a.lowmem == "y.utm" and a.count == -1
+
+
+def fixture_shard(names):
+    parts = [ou.load_part(n) for n in names]
+    dense, var_count, samples = npo.build_matrix(parts)
+    return FakeShard(npo.pack_columns(dense), dense.shape[0]), var_count, samples
+
+
+@pytest.mark.parametrize("name", ["select_intcnt", "select_exclude", "select_weights", "select_weights_subset", "select_tiny"])
+def test_run_selection_bookkeeping_matches_golden(name):
+    """run_selection/greedy_select (count resolution, subset/exclude masks, weights vector, totals,
+    pct rounding, row formatting) over a stand-in matrix = the reference's golden TSV."""
+    from utmos_amd import select as sel
+    case = ou.golden_cases()[name]
+    kw = ou.case_kwargs(case["args"])
+    shard, var_count, samples = fixture_shard(case["inputs"])
+    data = {"samples": samples, "data": shard, "var_count": var_count}
+    rows = sel.run_selection(data, kw.get("count", 0.02), kw.get("subset"), kw.get("exclude"), kw.get("weights"))
+    text = sel.HEADER + "".join("\t".join(str(x) for x in r) + "\n" for r in rows)
+    assert text == ou.golden_text(case)
+
+
+def test_greedy_select_updates_mask_in_place_and_stops():
+    from utmos_amd.select import greedy_select
+    shard, var_count, samples = fixture_shard(["tiny"])
+    mask = np.ones(len(samples), dtype="uint8")
+    rows = list(greedy_select(shard, var_count, 20, samples, mask))
+    assert len(rows) == 4 and rows[-1][4] == 1.0            # answer_key/select_tiny.txt: runs out after 4
+    assert (mask == 0).sum() == 4
+
+
+def test_shard_bounds_cover_everything():
+    from utmos_amd.sharded import shard_bounds
+    for n, w in ((2504, 8), (100000, 8), (7, 3), (5, 8)):
+        spans = [shard_bounds(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and sum(s[1] for s in spans) == n
+        assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from utmos_amd.sharded import TorchDistTransport, shard_bounds, sharded_greedy
+        rng = np.random.default_rng(21)
+        n_var, n_samp = 3000, 41
+        dense = ou.random_dense(rng, n_var, n_samp)
+        cols = npo.pack_columns(dense)
+        state = np.ones(n_samp, np.uint8)
+        state[[4, 30]] = 2
+        w = rng.choice([1.0, 2.0, 0.5], n_samp)
+        first, n_local = shard_bounds(n_samp, rank, world)
+        shard = FakeShard(cols, n_var, first, n_local)
+        shard.set_state(state)
+        shard.set_weights(w)
+        shard.reset()
+        got = list(sharded_greedy(shard, TorchDistTransport(), n_samp))
+        exp = ou.c_greedy(cols, n_var, state, w)
+        ok = [g[0] for g in got] == exp[0].tolist() and [g[1] for g in got] == exp[1].tolist() \
+            and [g[2] for g in got] == exp[2].tolist()
+        q.put((rank, ok, len(got)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_protocol_world_size_2_gloo():
+    """N > 1 path on CPU: two processes, gloo, each holding half of the samples; every rank must
+    produce the single-process sequence (records exchange + winner-column broadcast)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res) and res[0][2] == res[1][2] > 0
+
+
+def _socket_worker(rank, world, port, q):
+    from utmos_amd.sharded import SocketTransport, shard_bounds, sharded_greedy
+    tr = SocketTransport(rank, world, port=port)
+    try:
+        rng = np.random.default_rng(22)
+        n_var, n_samp = 2000, 23
+        dense = ou.random_dense(rng, n_var, n_samp)
+        cols = npo.pack_columns(dense)
+        first, n_local = shard_bounds(n_samp, rank, world)
+        shard = FakeShard(cols, n_var, first, n_local)
+        shard.reset()
+        got = list(sharded_greedy(shard, tr, n_samp))
+        exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8))
+        q.put((rank, [g[0] for g in got] == exp[0].tolist() and [g[1] for g in got] == exp[1].tolist()))
+    finally:
+        tr.close()
+
+
+def test_sharded_protocol_world_size_3_sockets():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_socket_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert sorted(r[0] for r in res) == [0, 1, 2] and all(r[1] for r in res)

@@ -1,0 +1,339 @@
+"""`utmos select` on MI355X: the host side of the greedy maximum-coverage selection.
+
+Mirrors the reference's module utmos/select.py function for function -- same names, argument
+meaning and stopping behaviour -- with the matrix living in HBM (device.DeviceMatrix) and the loop
+running in hand-written HIP kernels behind libutmos_hip.so:
+
+    calculate_scores   utmos/select.py:24-53    one scoring pass, stateless in sample_mask
+    greedy_select      utmos/select.py:69-137   generator of [name, var_count, new, tot, pct]
+    run_selection      utmos/select.py:147-195
+    load_files         utmos/select.py:241-321  (in-memory branch; the hdf5 branch -> packed .utm store)
+    parse_sample_lists / parse_weights / parse_args / select_main   utmos/select.py:327-448
+
+There is no CPU path: every scoring call goes through the C ABI and raises if the library or a GPU
+is missing.
+"""
+import argparse
+import json
+import logging
+import os
+import sys
+
+import numpy as np
+
+from . import device
+
+MAXMEM = 2  # GB of HBM a chunk of packed columns may take; 0 forces the smallest chunks (test hook, as select.py:18-19)
+
+HEADER = "sample\tvar_count\tnew_count\ttot_captured\tpct_captured\n"
+STORE_SUFFIX = ".utm"
+
+
+#############
+# Core code #
+#############
+def calculate_scores(matrix, sample_mask, sample_weights=None):
+    """Best scoring sample for the given mask: (column index, new_variant_count) or (None, None).
+
+    Stateless like the reference: covered variants are recomputed from sample_mask == 0.  The greedy
+    driver below does not call this per iteration (it keeps the loop on the device); it is the drop-in
+    for callers that do.
+    """
+    matrix.set_state(np.asarray(sample_mask))
+    matrix.set_weights(sample_weights)
+    counts, scores = matrix.peek_scores()
+    full = np.zeros(matrix.n_samples)
+    full[matrix.first_sample:matrix.first_sample + matrix.n_local] = scores
+    use_sample = np.argmax(full)
+    if full[use_sample] == 0:
+        return None, None
+    return use_sample, counts[use_sample - matrix.first_sample]
+
+
+def is_memsafe(shape, with_af=False):
+    """HBM estimate in GB of the packed matrix (+ AF table); True if it fits one chunk."""
+    data_size = (shape[0] * shape[1] / 8 + (shape[0] * 8 if with_af else 0)) / 1e9
+    logging.debug("Estimated packed size %.2fGB", data_size)
+    return data_size < MAXMEM
+
+
+##############
+# Algorithms #
+##############
+def greedy_select(matrix, total_variant_count, select_count, vcf_samples, sample_mask, sample_weights=None,
+                  batch=64):
+    """Greedy calculation; yields each selected sample's row.
+
+    matrix:              device.DeviceMatrix (bit-packed, HBM resident)
+    total_variant_count: total number of variants per sample
+    select_count:        how many samples to select
+    vcf_samples:         sample names, lines up with sample_mask
+    sample_mask:         1 = can be selected, 0 = used, 2 = excluded; updated in place like the reference
+    sample_weights:      optional per-sample weights
+    """
+    num_vars = matrix.shape[0]
+    tot_captured = 0
+    matrix.set_state(np.asarray(sample_mask))
+    matrix.set_weights(sample_weights)
+    matrix.reset()
+    remaining = int(select_count)
+    while remaining > 0:
+        want = min(batch, remaining)
+        idx, new, _ = matrix.run(want)          # device-resident: up to `want` iterations, no host round trips
+        for use_sample, new_variant_count in zip(idx, new):
+            tot_captured += new_variant_count   # np.int64, as in the reference
+            sample_mask[use_sample] = 0
+            yield [vcf_samples[use_sample], int(total_variant_count[use_sample]), int(new_variant_count),
+                   int(tot_captured), round(tot_captured / num_vars, 4)]
+        remaining -= len(idx)
+        if len(idx) < want:                     # the device loop stopped by itself
+            if tot_captured >= num_vars:
+                logging.warning("Ran out of new variants")
+            else:
+                logging.warning("Ran out of new variants (multi-allelics)")
+            return
+
+
+####################
+# Setup/Management #
+####################
+def run_selection(data, select_count=0.02, subset=None, exclude=None, weights=None):
+    """Set up the selection: select_count in [0,1) = fraction, >= 1 = count, < 0 = all."""
+    num_vars, num_samples = data["data"].shape
+    logging.info("Sample Count %d", num_samples)
+    logging.info("Variant Count %d", num_vars)
+
+    select_count = num_samples if select_count < 0 \
+        else max(1, int(num_samples * select_count) if select_count < 1 else int(select_count))
+    logging.info("Selecting %d samples", select_count)
+
+    vcf_samples = np.asarray(data["samples"]).astype(str)
+
+    # 1 = can use, 0 = mask, 2 = exclude
+    sample_mask = np.ones(num_samples, dtype="uint8")
+    if subset:
+        sample_mask = np.where(np.isin(vcf_samples, subset), 1, 2).astype("uint8")
+        logging.info("Subsetting to %d samples", len(subset))
+    if exclude:
+        sample_mask = np.where(np.isin(vcf_samples, exclude), 2, sample_mask).astype("uint8")
+        logging.info("Excluding %d samples", len(exclude))
+    if subset and exclude:
+        logging.info("Ending with %d samples", len(sample_mask) - (sample_mask == 1).sum())
+
+    sample_weights = None
+    if weights is not None:
+        logging.info("Setting %d weights", len(weights))
+        sample_weights = np.ones(num_samples)
+        for pos, name in enumerate(vcf_samples):
+            if name in weights:
+                sample_weights[pos] = weights[name]
+
+    return greedy_select(data["data"], np.asarray(data["var_count"]), select_count, vcf_samples, sample_mask,
+                         sample_weights)
+
+
+def _read_part(path):
+    if path.endswith((".vcf.gz", ".vcf")):
+        from .vcfio import read_vcf
+        return read_vcf(path)
+    if path.endswith(".jl"):
+        import joblib  # the reference's own container (utmos/convert.py:98)
+        return joblib.load(path)
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return {"GT": z["GT"], "AF": z["AF"], "samples": z["samples"]}
+    logging.error("Unknown filetype %s. Expected `.vcf[.gz]`, `.jl`, `.npz`", path)
+    sys.exit(1)
+
+
+def save_store(path, data, af_parts):
+    """Packed column store (the hdf5 replacement): samples, var_count and per chunk the column bitsets
+    (+ float32 AF, the dtype the reference's hdf5 holds, select.py:218-223)."""
+    matrix = data["data"]
+    arrays = {"samples": np.asarray(data["samples"]).astype("U"), "var_count": np.asarray(data["var_count"]),
+              "chunk_vars": np.asarray(matrix.chunk_vars, dtype=np.int64), "has_af": np.asarray(af_parts is not None)}
+    for c in range(len(matrix.chunk_vars)):
+        arrays[f"cols{c}"] = matrix.download_columns(c)
+        if af_parts is not None:
+            arrays[f"af{c}"] = np.asarray(af_parts[c], dtype=np.float32)
+    with open(path, "wb") as fh:
+        np.savez(fh, **arrays)
+
+
+def load_store(path, dev=0):
+    with np.load(path, allow_pickle=False) as z:
+        samples = z["samples"]
+        matrix = device.DeviceMatrix(len(samples), device=dev)
+        has_af = bool(z["has_af"])
+        for c, n_var in enumerate(z["chunk_vars"]):
+            idx = matrix.add_chunk(int(n_var))
+            matrix.upload_columns(idx, z[f"cols{c}"])
+            if has_af:
+                matrix.set_af(idx, z[f"af{c}"])
+        return {"samples": samples, "data": matrix, "var_count": z["var_count"], "has_af": has_af}
+
+
+# pylint: disable=too-many-locals
+def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0):
+    """Load and concatenate inputs into one HBM-resident matrix.
+
+    lowmem == 1: in_files[0] is an existing packed store.  lowmem == path: the store is (re)created
+    there; like the reference's hdf5 it keeps AF as float32, so `--lowmem` + `--af` scores with
+    float32 AF values (answer_key/select_af_h5.txt), the plain path with float64 (select_af.txt).
+    `buffer` = variants per chunk when chunking is forced.
+    """
+    logging.info("Loading %d files", len(in_files))
+    if lowmem == 1:
+        return load_store(in_files[0], dev)
+
+    samples = None
+    matrix = None
+    af_parts = []
+    for load_count, path in enumerate(in_files):
+        dat = _read_part(path)
+        if samples is None:
+            samples = np.asarray(dat["samples"]).astype("U")
+            matrix = device.DeviceMatrix(len(samples), device=dev)
+        rows = np.ascontiguousarray(dat["GT"], dtype=np.uint8)
+        informative = rows.any(axis=1)          # a row without carriers has no set bit in any byte
+        logging.debug("fitering %d uninformative variants", int((~informative).sum()))
+        rows = rows[informative]
+        af = np.asarray(dat["AF"], dtype=np.float64).reshape(-1)[informative]
+        # one chunk per `step` variants: everything in one chunk unless the estimate says otherwise
+        step = len(rows) if (MAXMEM != 0 and is_memsafe((len(rows), len(samples)), calc_af)) else max(64, buffer // 64 * 64)
+        for lo in range(0, len(rows), step):
+            part = rows[lo:lo + step]
+            chunk = matrix.add_chunk(len(part))
+            matrix.upload_rows_packed(chunk, part)
+            af_parts.append(af[lo:lo + step])
+        logging.debug("Loaded %d of %d", load_count + 1, len(in_files))
+
+    ret = {"samples": samples, "data": matrix}
+    ret["var_count"] = matrix.var_count()       # before AF == 0 rows are cleared, like select.py:281-284
+    if calc_af:
+        as32 = lowmem is not None
+        for chunk, af in enumerate(af_parts):
+            matrix.set_af(chunk, af.astype(np.float32) if as32 else af)
+    ret["has_af"] = bool(calc_af)
+    if lowmem is not None:
+        save_store(lowmem, ret, af_parts if calc_af else None)
+    return ret
+# pylint: enable=too-many-locals
+
+
+###################
+# Input utilities #
+###################
+def parse_sample_lists(argument):
+    """--exclude/--subset: file names and/or comma separated lists."""
+    ret = []
+    if not argument:
+        return ret
+    for i in argument:
+        if os.path.exists(i):
+            with open(i, "r") as fh:
+                ret.extend([_.strip() for _ in fh])
+        else:
+            ret.extend(i.split(","))
+    return ret
+
+
+def parse_weights(argument):
+    """Tab-delimited `sample<TAB>weight` -> {sample: weight}."""
+    if not argument:
+        return None
+    ret = {}
+    with open(argument, "r") as fh:
+        for line in fh:
+            if not line.strip():
+                continue
+            name, weight = line.rstrip("\n").split("\t")[:2]
+            ret[name] = float(weight)
+    return ret
+
+
+def setup_logging(debug=False):
+    logging.basicConfig(stream=sys.stderr, level=logging.DEBUG if debug else logging.INFO,
+                        format="%(asctime)s [%(levelname)s] %(message)s", force=True)
+
+
+def parse_args(args):
+    """Same flags as the reference (utmos/select.py:355-418); `.utm` takes the place of `.hdf5`."""
+    parser = argparse.ArgumentParser(prog="select", description=__doc__,
+                                     formatter_class=argparse.RawDescriptionHelpFormatter)
+    parser.add_argument("in_files", nargs="*", type=str, help="Input VCF, jl or npz files")
+    parser.add_argument("-c", "--count", type=float, default=0.02,
+                        help="Number of samples to select as a percent if <1 or count if >=1 or -1 for all (%(default)s)")
+    parser.add_argument("-o", "--out", type=str, default="/dev/stdout", help="Output file (stdout)")
+    parser.add_argument("--debug", action="store_true", help="Verbose logging")
+
+    scoreg = parser.add_argument_group("Scoring Arguments")
+    scoreg.add_argument("--af", action="store_true", help="Weigh variants by allele frequency")
+    scoreg.add_argument("--weights", type=str, default=None, help="Tab-delimited file of sample weights")
+    scoreg.add_argument("--subset", type=str, default=None, action="append",
+                        help="Filename with or Comma-separated list of samples to analyze")
+    scoreg.add_argument("--exclude", type=str, default=None, action="append",
+                        help="Filename with or Comma-separated list of samples to exclude selection")
+
+    mperfg = parser.add_argument_group("Memory Arguments")
+    mperfg.add_argument("--lowmem", type=str, default=None,
+                        help="Name of packed matrix store (.utm) to create/use (%(default)s)")
+    mperfg.add_argument("--buffer", type=int, default=32768,
+                        help="Number of variants per chunk when chunking (%(default)s)")
+    mperfg.add_argument("--maxmem", type=int, default=2,
+                        help="Maximum HBM (GB) of one chunk. 0 forces chunking (%(default)s)")
+    mperfg.add_argument("--device", type=int, default=0, help="GPU to use (%(default)s)")
+
+    args = parser.parse_args(args)
+    setup_logging(args.debug)
+    if [_ for _ in args.in_files if _.endswith((STORE_SUFFIX, ".hdf5"))] and len(args.in_files) > 1:
+        logging.error("Cannot provide a matrix store with multiple input files")
+        sys.exit(1)
+    if [_ for _ in args.in_files if _.endswith(".hdf5")] or (args.lowmem or "").endswith(".hdf5"):
+        logging.error("hdf5 stores are not read by this build; recreate with --lowmem FILE%s", STORE_SUFFIX)
+        sys.exit(1)
+
+    if len(args.in_files) == 0:
+        if not args.lowmem:
+            logging.error("No input files provided")
+            sys.exit(1)
+        args.in_files = [args.lowmem]
+        args.lowmem = 1
+
+    if len(args.in_files) == 1 and args.in_files[0].endswith(STORE_SUFFIX) and not args.lowmem:
+        logging.info("Switching on lowmem for store input")
+        args.lowmem = 1
+
+    logging.info("Params:\n%s", json.dumps(vars(args), indent=4))
+    return args
+
+
+def select_main(cmdargs):
+    """Main"""
+    global MAXMEM  # pylint: disable=global-statement
+    args = parse_args(cmdargs)
+    MAXMEM = args.maxmem
+    for path in args.in_files:
+        if not os.path.exists(path):
+            logging.error("Input %s does not exist", path)
+            sys.exit(1)
+
+    data = load_files(args.in_files, args.lowmem, args.buffer, args.af, args.device)
+    if not data["has_af"] and args.af:
+        logging.critical("Store doesn't appear to be created with --af weighted scores, remove --af or recreate it")
+        sys.exit(1)
+    if data["has_af"] and not args.af:
+        logging.critical("Store appears to be created with --af weighted scores, add --af or recreate it")
+
+    args.subset = parse_sample_lists(args.subset)
+    args.exclude = parse_sample_lists(args.exclude)
+    args.weights = parse_weights(args.weights)
+
+    with open(args.out, "w") as fout:
+        fout.write(HEADER)
+        for result in run_selection(data, args.count, args.subset, args.exclude, args.weights):
+            logging.info("Selected %s (%.1f%% of variants)", result[0], result[4] * 100)
+            fout.write("\t".join([str(_) for _ in result]) + "\n")
+            fout.flush()
+    data["data"].close()
+    logging.info("Finished utmos")

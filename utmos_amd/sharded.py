@@ -1,0 +1,158 @@
+"""Sample-axis sharding of the greedy loop.
+
+Each rank holds a contiguous block of sample columns and a full replica of the covered mask.  One
+iteration = local scoring -> every rank's best (score, global idx, new_count) record exchanged ->
+the same winner chosen on every rank (score descending, index ascending = np.argmax's first maximum,
+utmos/select.py:48) -> the winner's column reaches every rank -> covered |= column.
+
+Two transports:
+  * fused (production): `DeviceMatrix.comm_init` + `run()` -- one ncclAllGather per iteration carrying
+    {record, candidate column} of every rank, all on the GPU stream, no host round trip;
+  * host staged (this module): the same protocol driven from Python through the C ABI's building
+    blocks (utm_local_best / utm_get_column / utm_apply_records) over any object with `allgather`
+    and `broadcast` -- used with torch.distributed (gloo) in tests and on hosts without RCCL.
+"""
+import numpy as np
+
+
+def shard_bounds(n_samples, rank, world):
+    """Contiguous, near-equal blocks; lower rank = lower sample indices (keeps the tie-break global)."""
+    first = rank * n_samples // world
+    return first, (rank + 1) * n_samples // world - first
+
+
+def pick_winner(records):
+    """records: [(score, idx, new)] in rank order -> winning rank or None."""
+    best = None
+    for rank, (score, idx, _new) in enumerate(records):
+        if idx < 0:
+            continue
+        if best is None or score > records[best][0] or (score == records[best][0] and idx < records[best][1]):
+            best = rank
+    return best
+
+
+class TorchDistTransport:
+    """allgather/broadcast over torch.distributed (gloo on CPU tensors)."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def allgather(self, record):
+        t = self.torch.tensor([float(record[0]), float(record[1]), float(record[2])], dtype=self.torch.float64)
+        out = [self.torch.zeros(3, dtype=self.torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        return [(float(o[0]), int(o[1]), int(o[2])) for o in out]
+
+    def broadcast(self, column, n_words, src):
+        buf = self.torch.from_numpy(column.view(np.int64)) if column is not None \
+            else self.torch.zeros(n_words, dtype=self.torch.int64)
+        self.dist.broadcast(buf, src=src, group=self.group)
+        return buf.numpy().view(np.uint64)
+
+
+class SocketTransport:
+    """allgather/broadcast over plain TCP sockets (star through rank 0); no third-party dependency,
+    so GPU processes never have to load a second HIP runtime next to libutmos_hip.so."""
+
+    def __init__(self, rank, world, addr="127.0.0.1", port=29617, timeout=300.0):
+        import socket
+        import struct
+        import time
+        self.rank, self.world, self._struct = rank, world, struct
+        self.peers = []
+        if world == 1:
+            return
+        if rank == 0:
+            srv = socket.socket()
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            by_rank = {}
+            while len(by_rank) < world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                by_rank[struct.unpack("<i", self._recv(conn, 4))[0]] = conn
+            srv.close()
+            self.peers = [by_rank[r] for r in range(1, world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    conn = socket.create_connection((addr, port), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            conn.sendall(struct.pack("<i", rank))
+            self.peers = [conn]
+
+    @staticmethod
+    def _recv(conn, n):
+        buf = bytearray()
+        while len(buf) < n:
+            part = conn.recv(n - len(buf))
+            if not part:
+                raise ConnectionError("peer closed the connection")
+            buf += part
+        return bytes(buf)
+
+    def allgather(self, record):
+        pack = self._struct.Struct("<dqq")
+        mine = pack.pack(float(record[0]), int(record[1]), int(record[2]))
+        if self.world == 1:
+            return [pack.unpack(mine)]
+        if self.rank == 0:
+            blob = mine + b"".join(self._recv(c, pack.size) for c in self.peers)
+            for c in self.peers:
+                c.sendall(blob)
+        else:
+            self.peers[0].sendall(mine)
+            blob = self._recv(self.peers[0], pack.size * self.world)
+        return [pack.unpack_from(blob, r * pack.size) for r in range(self.world)]
+
+    def broadcast(self, column, n_words, src):
+        n = n_words * 8
+        if self.rank == 0:
+            data = column.tobytes() if src == 0 else self._recv(self.peers[src - 1], n)
+            for r, c in enumerate(self.peers, start=1):
+                if r != src:
+                    c.sendall(data)
+        else:
+            if self.rank == src:
+                self.peers[0].sendall(column.tobytes())
+                return column
+            data = self._recv(self.peers[0], n)
+        return np.frombuffer(data, dtype=np.uint64).copy()
+
+    def close(self):
+        for c in self.peers:
+            c.close()
+
+
+def sharded_greedy(shard, transport, select_count):
+    """Yield (global idx, new_count, score) per selected sample; identical on every rank.
+
+    `shard` is this rank's matrix (DeviceMatrix with first_sample/n_local set, state and weights
+    already applied, reset done)."""
+    n_words = shard.column_words()
+    for _ in range(int(select_count)):
+        records = transport.allgather(shard.local_best())
+        owner = pick_winner(records)
+        if owner is None:
+            return
+        column = None
+        if transport.world > 1:
+            mine = shard.get_column(records[owner][1]) if transport.rank == owner else None
+            column = transport.broadcast(mine, n_words, owner)
+        out = shard.apply_records(records, None if transport.rank == owner else column)
+        if out is None:
+            return
+        yield out
