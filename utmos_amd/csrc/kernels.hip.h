@@ -13,6 +13,7 @@
 typedef unsigned long long u64;
 typedef long long i64;
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));  // one global_load_dwordx4 / ds_read_b128
+typedef unsigned long long v2q __attribute__((ext_vector_type(2)));
 
 #define UTM_HDR_WORDS 8  // one utm_record (64 B) in front of every exchanged column
 #define UTM_STEP_WORDS 128  // words one wave instruction covers (64 lanes x 2)
@@ -36,17 +37,26 @@ struct Rec {  // == utm_record
     i64 pad[5];
 };
 
+// Wave64 sum with DPP row shifts + row broadcasts (gfx9 family: row_bcast:15/31 exist); the total ends
+// up in lane 63 and is returned wave-uniformly.  6 VALU ops, no LDS crossbar traffic.
 __device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ i64 wave_sum_i64(i64 v)
+// 64-bit sums as three 32-bit reductions over 21-bit pieces (wave sums of a piece stay below 2^27);
+// per-lane values must be below 2^63.
+__device__ __forceinline__ i64 wave_sum_u63(u64 v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    const unsigned p0 = wave_sum_u32((unsigned)(v & 0x1FFFFFu));
+    const unsigned p1 = wave_sum_u32((unsigned)((v >> 21) & 0x1FFFFFu));
+    const unsigned p2 = wave_sum_u32((unsigned)(v >> 42));
+    return (i64)(((u64)p2 << 42) + ((u64)p1 << 21) + p0);
 }
 
 // Winner column of the previous iteration for words [w0, ...) of a chunk, or nullptr.
@@ -129,19 +139,23 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1-AF (float32 AF as exact fixed point): besides the count, afsum[s] +=
-// sum of AFq[v] over the set, uncovered bits, AFq = AF * 2^q as int64.  Tile = 8192 variants: the
-// AFq tile (64 KiB) and ~covered (1 KiB) sit in LDS, a wave reads 1 KiB of one sample per step and
-// walks the surviving bits (ctz / clear-lowest / ds_read_b64 gather / 64-bit add).
+// K1-AF (float32 AF as exact fixed point): besides the count, afsum[s] += the
+// sum of AF[v] * 2^q as int64 over the set, uncovered bits.  Tile = 8192 variants = one KiB of every
+// column: the float32 AF tile (32 KiB) and ~covered (1 KiB) sit in LDS; a wave keeps 4 samples' KiB
+// in flight, skips samples whose KiB has no surviving bit (the common case once coverage has grown),
+// otherwise walks the bits (ctz / clear-lowest / ds_read_b32 gather / mantissa << exponent / 64-bit add).
+// A float32 a = m * 2^(e-150) (m = 24-bit mantissa with the hidden bit, e = biased exponent), so
+// a * 2^q = m << (e - e_base), e_base = 150 - q >= the smallest exponent present (host checks).
 // ------------------------------------------------------------------------------------------------
 #define UTM_AF_TILE_WORDS 128
 __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
-                                                   const i64 *__restrict__ afq, const u64 *__restrict__ xbuf,
-                                                   u64 slot_words, u64 chunk_off, const IterState *__restrict__ st,
-                                                   const unsigned *__restrict__ act, u64 *__restrict__ cnt,
-                                                   i64 *__restrict__ afsum, unsigned group_size, unsigned n_groups)
+                                                   const float *__restrict__ af, int e_base,
+                                                   const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                                   const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                   u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
+                                                   unsigned n_groups)
 {
-    __shared__ i64 aq[UTM_AF_TILE_WORDS * 64];
+    __shared__ unsigned aft[UTM_AF_TILE_WORDS * 64];  // float32 bit patterns
     __shared__ u64 live[UTM_AF_TILE_WORDS];
     if (st->done) return;
     const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
@@ -156,9 +170,10 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
         live[threadIdx.x] = ~c;
     }
     {
-        const int4 *src = reinterpret_cast<const int4 *>(afq + w0 * 64);
-        int4 *dst = reinterpret_cast<int4 *>(aq);
-        for (int i = threadIdx.x; i < UTM_AF_TILE_WORDS * 32; i += 256) dst[i] = src[i];
+        const v4u *src = reinterpret_cast<const v4u *>(af + w0 * 64);
+        v4u *dst = reinterpret_cast<v4u *>(aft);
+#pragma unroll
+        for (int i = 0; i < UTM_AF_TILE_WORDS * 16 / 256; ++i) dst[i * 256 + threadIdx.x] = src[i * 256 + threadIdx.x];
     }
     __syncthreads();
 
@@ -167,21 +182,40 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
     const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u64 m0 = live[2 * lane], m1 = live[2 * lane + 1];
-    const i64 *a0 = aq + (2 * lane) * 64, *a1 = a0 + 64;
-    for (unsigned i = lo + wave; i < hi; i += 4) {
-        const unsigned s = act[i];
-        const ulonglong2 x = *(reinterpret_cast<const ulonglong2 *>(cols + (u64)s * wp + w0) + lane);
-        u64 b0 = x.x & m0, b1 = x.y & m1;
-        unsigned n = __popcll(b0) + __popcll(b1);
-        i64 sum = 0;
-        while (b0) { sum += a0[__builtin_ctzll(b0)]; b0 &= b0 - 1; }
-        while (b1) { sum += a1[__builtin_ctzll(b1)]; b1 &= b1 - 1; }
-        n = wave_sum_u32(n);
-        if (n) {  // wave uniform
-            sum = wave_sum_i64(sum);
+    const unsigned *a0 = aft + (2 * lane) * 64, *a1 = a0 + 64;
+    constexpr int U = 4;
+    for (unsigned i0 = lo + wave * U; i0 < hi; i0 += 4 * U) {
+        unsigned s[U];
+        v2q x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u < hi ? i0 + u : hi - 1;  // tail: re-read the last sample, ignored below
+            s[u] = act[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            x[u] = __builtin_nontemporal_load(reinterpret_cast<const v2q *>(cols + (u64)s[u] * wp + w0) + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            u64 b0 = x[u].x & m0, b1 = x[u].y & m1;
+            const unsigned n_lane = __popcll(b0) + __popcll(b1);
+            if (i0 + u >= hi || __ballot(n_lane != 0) == 0) continue;  // wave uniform
+            u64 sum = 0;
+            while (b0) {
+                const unsigned bits = a0[__builtin_ctzll(b0)];
+                b0 &= b0 - 1;
+                sum += (u64)((bits & 0x7FFFFFu) | 0x800000u) << ((bits >> 23) - e_base);
+            }
+            while (b1) {
+                const unsigned bits = a1[__builtin_ctzll(b1)];
+                b1 &= b1 - 1;
+                sum += (u64)((bits & 0x7FFFFFu) | 0x800000u) << ((bits >> 23) - e_base);
+            }
+            const unsigned n = wave_sum_u32(n_lane);
+            const i64 total = wave_sum_u63(sum);  // per lane < 2^53 (the host's exactness precondition)
             if (lane == 0) {
-                atomicAdd(&cnt[s], (u64)n);
-                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), (u64)sum);
+                atomicAdd(&cnt[s[u]], (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s[u]]), (u64)total);
             }
         }
     }

@@ -506,14 +506,7 @@ static int build_af_tables(utm_ctx *c)
             c->af_q = q;
         }
     }
-    if (c->af_fixed) {
-        for (auto &ch : c->chunks) {
-            std::vector<i64> q(ch.wp * 64, 0);
-            for (u64 v = 0; v < ch.n_var; ++v) q[v] = (i64)ldexp((double)ch.h_af32[v], c->af_q);
-            HIP_TRY(hipMalloc(&ch.afq, q.size() * 8));
-            HIP_TRY(hipMemcpy(ch.afq, q.data(), q.size() * 8, hipMemcpyHostToDevice));
-        }
-    } else {
+    {
         std::vector<SeqChunk> seq;
         for (auto &ch : c->chunks) {
             const size_t esz = c->af_mode == UTM_AF_F32 ? 4 : 8;
@@ -524,8 +517,10 @@ static int build_af_tables(utm_ctx *c)
                               ch.n_var * esz, hipMemcpyHostToDevice));
             seq.push_back(SeqChunk{ch.cols, ch.covered, ch.af, ch.wp, ch.w});
         }
-        HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
-        HIP_TRY(hipMemcpy(c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
+        if (!c->af_fixed) {
+            HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
+            HIP_TRY(hipMemcpy(c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
+        }
     }
     c->dirty_tables = false;
     return UTM_OK;
@@ -644,7 +639,7 @@ static int enqueue_score(utm_ctx *c)
 {
     const unsigned a_ub = std::max(1u, c->active_ub);
     const u64 slot = c->xbuf_slot_words;
-    static const int target_wgs = tune_env("UTM_TARGET_WGS", 4096);
+    static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
     static const int min_wgs = tune_env("UTM_MIN_WGS", 1024);
     static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
     static const int use_nt = tune_env("UTM_NT_LOADS", 1);
@@ -684,11 +679,14 @@ static int enqueue_score(utm_ctx *c)
             if (c->af_mode != UTM_AF_NONE) {
                 const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
                 // few, large groups: every workgroup re-stages its 64 KiB AF tile
-                unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)target_wgs / std::max<u64>(1, tiles)));
-                unsigned group = ((a_ub + n_groups - 1) / n_groups + 3) / 4 * 4;
+                // every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache): groups of >= 64 samples
+                static const int af_target = tune_env("UTM_AF_TARGET_WGS", 16384);
+                unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)af_target / std::max<u64>(1, tiles)));
+                unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
                 n_groups = (a_ub + group - 1) / group;
                 hipLaunchKernelGGL(k_score_afq, dim3((unsigned)(tiles * n_groups)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                                   ch.afq, c->d_xbuf, slot, ch.off, c->d_st, c->d_act, c->d_cnt, c->d_afsum, group, n_groups);
+                                   static_cast<const float *>(ch.af), 150 - c->af_q, c->d_xbuf, slot, ch.off, c->d_st, c->d_act,
+                                   c->d_cnt, c->d_afsum, group, n_groups);
             } else {
                 const u64 steps_total = ch.wp / UTM_STEP_WORDS;
                 const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
