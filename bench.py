@@ -22,6 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_START = time.time()
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -35,10 +36,13 @@ def parse():
     p.add_argument("--select", type=int, default=-1, help="samples to select per step (-1 = all)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--af", action="store_true", help="configs[2]: float32 AF weighting")
+    p.add_argument("--af-dtype", choices=["f32", "f64"], default="f32",
+                   help="f32 = the reference's hdf5 values (configs[2]); f64 = its in-memory values")
     p.add_argument("--chunk-vars", type=int, default=0, help="split the variant axis into chunks of this many variants")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
     p.add_argument("--no-roofline-pass", action="store_true")
+    p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the exchange path)")
     return p.parse_args()
 
 
@@ -56,10 +60,11 @@ def rendezvous_id(rank, world, make_id):
     deadline = time.time() + 300
     while time.time() < deadline:
         try:
-            with open(path, "rb") as fh:
-                uid = fh.read()
-            if len(uid) == 128:
-                return uid, path
+            if os.path.getmtime(path) >= T_START - 600:      # never a leftover of an older launch
+                with open(path, "rb") as fh:
+                    uid = fh.read()
+                if len(uid) == 128:
+                    return uid, path
         except FileNotFoundError:
             pass
         time.sleep(0.05)
@@ -133,10 +138,11 @@ def main():
         m.synth_fill(c, seed=args.seed, first_var_global=v0)
         if args.af:
             _, af = device.synth_host(args.seed, nv, n_total, first_var_global=v0, want_cols=False)
-            m.set_af(c, af)
+            # f64: full 53-bit mantissas, like the reference's ac/an quotients
+            m.set_af(c, af if args.af_dtype == "f32" else af.astype(np.float64) / 3.0)
         v0 += nv
     t_gen = time.perf_counter() - t_gen
-    if world > 1:
+    if world > 1 or args.force_comm:
         uid, id_path = rendezvous_id(rank, world, device.DeviceMatrix.comm_unique_id)
         m.comm_init(rank, world, uid)
     k_sel = n_total if args.select < 0 else min(args.select, n_total)
@@ -182,7 +188,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, bitset = cpu_baseline(args, device)
 
-    if world > 1 and rank == 0:
+    if (world > 1 or args.force_comm) and rank == 0:
         try:
             os.remove(id_path)
         except OSError:
@@ -196,13 +202,13 @@ def main():
         "metric": "greedy iterations/sec + achieved HBM GB/s, 10M variants x 2.5k samples",
         "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32+u64" if args.af else "u64", "data": "synthetic",
+        "vs_baseline": None, "dtype": (args.af_dtype + "+u64") if args.af else "u64", "data": "synthetic",
         "config": {"workload": f"synthetic {args.n_var} variants x {n_total} samples bit-matrix, select "
-                               f"{'all' if args.select < 0 else k_sel}{', --af float32' if args.af else ''}",
+                               f"{'all' if args.select < 0 else k_sel}{(', --af ' + args.af_dtype) if args.af else ''}",
                    "n_var": args.n_var, "n_samp": n_total, "iterations_per_step": iters // max(1, args.steps),
                    "tot_captured": tot_captured, "chunks": st["n_chunks"], "seed": args.seed,
                    "sharding": f"sample axis over {world} GPU(s), one ncclAllGather per iteration" if world > 1 else "none",
-                   "generator_s": round(t_gen, 3)},
+                   "generator_s": round(t_gen, 3), "af_verified_parallel": st["af_fixed_point"] if args.af else None},
         "hbm_gbps_whole_loop": whole_loop_gbps, "hbm_frac_whole_loop": whole_loop_gbps / (HBM_PEAK_GBPS * world),
         "device_loop_ms_per_step": loop_ms / max(1, args.steps),
         "roofline": roofline, "cpu_baseline": cpu, "cpu_bitset_baseline": bitset,

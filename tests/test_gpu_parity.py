@@ -147,17 +147,47 @@ def test_af_modes(dev, mode):
         af = af.astype(np.float32)
     w = rng.choice([0.5, 1.0, 2.0], n_samp)
     _, stats = check_run(dev, dense, af=af, af_sequential=(mode == "f32_seq"))
-    assert stats["af_fixed_point"] == (1 if mode == "f32" else 0)
+    assert stats["af_fixed_point"] == (0 if mode == "f32_seq" else 1)     # 1 = verified-parallel scheme
     check_run(dev, dense, af=af, weights=w, af_sequential=(mode == "f32_seq"), k=40)
 
 
-def test_af_f32_falls_back_when_not_exactly_summable(dev):
+def test_af_f32_falls_back_when_not_representable(dev):
     rng = np.random.default_rng(10)
     dense = ou.random_dense(rng, 2000, 50)
     af = rng.random(2000).astype(np.float32)
-    af[0] = np.float32(1e-30)                       # tiny exponent: q too large for exact fixed point
+    af[0] = np.float32(1e-30)                       # exponent span too wide for int64 fixed point
     _, stats = check_run(dev, dense, af=af)
-    assert stats["af_fixed_point"] == 0
+    assert stats["af_fixed_point"] == 0             # sequential kernel, still bit exact
+
+
+def test_af_f32_sums_beyond_exact_range_use_chains(dev):
+    """float32 AFs whose running sums leave the range where float64 adds are exact (sum * 2^q >= 2^53):
+    the reference's result depends on the order of its adds; candidates are re-summed sequentially."""
+    rng = np.random.default_rng(16)
+    n_var, n_samp = 12000, 80
+    dense = rng.random((n_var, n_samp)) < 0.3
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    af = np.exp2(rng.uniform(-12, -8, n_var)).astype(np.float32)
+    af[:40] = np.float32(2.0 ** -30) * (1 + rng.random(40).astype(np.float32))   # q = 53: exact only below 1.0
+    got, stats = check_run(dev, dense, af=af)
+    assert stats["af_fixed_point"] == 1 and got[2][0] > 1.0
+    w = rng.choice([0.5, 1.0, -1.0, 3.0], n_samp)
+    check_run(dev, dense, af=af, weights=w, k=30)
+
+
+@pytest.mark.parametrize("kind", ["f32", "f64"])
+def test_af_many_exact_ties_overflow_the_candidate_list(dev, kind):
+    """100 identical columns tie in every iteration: more candidates than the chain kernel takes, so the
+    sequential re-scoring of everyone decides (f64), or the exact estimate does (f32)."""
+    rng = np.random.default_rng(17)
+    n_var, n_samp = 5000, 100
+    base = rng.random(n_var) < 0.2
+    base[:10] = True
+    dense = np.repeat(base[:, None], n_samp, axis=1)
+    dense[rng.integers(0, n_var, 300), rng.integers(0, n_samp, 300)] ^= True     # a few differences
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    af = (rng.random(n_var) * 0.5 + 1e-3)
+    check_run(dev, dense, af=af.astype(np.float32) if kind == "f32" else af, k=12)
 
 
 def test_multi_chunk_equals_single_chunk(dev):

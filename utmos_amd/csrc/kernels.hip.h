@@ -28,6 +28,18 @@ struct IterState {
     i64 iter;           // rows produced so far
     i64 tot;            // tot_captured
     i64 n_active_total; // selectable samples over all shards
+    // verified-parallel AF scoring (k_cand / k_chain)
+    int n_cand;         // candidates whose score interval reaches the best lower bound
+    int need_chain;     // some candidate's parallel sum is not provably the reference's float64 sum
+    int cand_overflow;  // more candidates than UTM_MAX_CAND: every sample is re-scored sequentially
+};
+
+#define UTM_MAX_CAND 64
+struct CandBuf {
+    unsigned pos[UTM_MAX_CAND];   // position in act[]
+    unsigned samp[UTM_MAX_CAND];  // local sample
+    i64 cnt[UTM_MAX_CAND];
+    double val[UTM_MAX_CAND];     // unweighted score: exact estimate (k_cand) or sequential float64 sum (k_chain)
 };
 
 struct Rec {  // == utm_record
@@ -36,6 +48,47 @@ struct Rec {  // == utm_record
     i64 new_count;
     i64 pad[5];
 };
+
+struct SeqChunk {
+    const u64 *cols;
+    const u64 *covered;
+    const void *af;
+    u64 wp;
+    u64 w;  // words holding variants
+};
+
+struct Cand {
+    double val;
+    i64 gidx;
+    i64 cnt;
+    unsigned pos;
+};
+
+struct PickArgs {
+    IterState *st;
+    unsigned *act;
+    unsigned char *state;
+    const double *weights;  // n_samp_total, or nullptr
+    u64 *cnt;
+    i64 *afsum;      // fixed-point AF sums, or nullptr
+    double *fscore;  // sequential AF scores, or nullptr
+    double af_scale; // 2^-q
+    CandBuf *cand;   // verified-parallel AF: candidate list, else nullptr
+    int af_is_f64;   // the estimate sums float32-rounded values of float64 AFs
+    Rec *recs;       // exchange slot headers: recs[r] at xbuf + r*slot_words
+    u64 slot_words;
+    i64 *res_idx;
+    i64 *res_new;
+    double *res_score;
+    i64 n_var_total;
+    unsigned first, n_local, n_total;
+    int rank, n_ranks;
+};
+
+__device__ __forceinline__ Rec *rec_of(const PickArgs &a, int r)
+{
+    return reinterpret_cast<Rec *>(reinterpret_cast<u64 *>(a.recs) + (u64)r * a.slot_words);
+}
 
 // Wave64 sum with DPP row shifts + row broadcasts (gfx9 family: row_bcast:15/31 exist); the total ends
 // up in lane 63 and is returned wave-uniformly.  6 VALU ops, no LDS crossbar traffic.
@@ -48,6 +101,17 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Inclusive prefix sum over the 64 lanes (same DPP ladder, every lane keeps its partial).
+__device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);
+    return v;
 }
 // 64-bit sums as three 32-bit reductions over 21-bit pieces (wave sums of a piece stay below 2^27);
 // per-lane values must be below 2^63.
@@ -227,19 +291,13 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 // float64 addition does not reassociate, so each sample's chain is walked by ONE lane, chunk after
 // chunk, word after word, bit after bit.  Latency bound by construction.
 // ------------------------------------------------------------------------------------------------
-struct SeqChunk {
-    const u64 *cols;
-    const u64 *covered;
-    const void *af;
-    u64 wp;
-    u64 w;  // words holding variants
-};
 template <typename AF_T>
 __global__ __launch_bounds__(64) void k_score_seq(const SeqChunk *__restrict__ chunks, int n_chunks,
                                                   const IterState *__restrict__ st, const unsigned *__restrict__ act,
-                                                  u64 *__restrict__ cnt, double *__restrict__ fscore)
+                                                  u64 *__restrict__ cnt, double *__restrict__ fscore, int only_on_overflow)
 {
     if (st->done) return;
+    if (only_on_overflow && !(st->need_chain && st->cand_overflow)) return;
     const unsigned i = blockIdx.x * 64 + threadIdx.x;
     if (i >= st->n_active) return;
     const unsigned s = act[i];
@@ -282,15 +340,157 @@ __global__ __launch_bounds__(256) void k_or_column(u64 *__restrict__ covered, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Verified-parallel AF scoring.  The reference's AF score of a sample is a float64 running sum in
+// ascending variant order (select.py:40); float64 addition does not reassociate, so a parallel sum is
+// only an *estimate* E with a rigorous bound B on |reference - E|:
+//   float32 AF: E = exact integer sum of AF*2^q.  While E < 2^53 every partial sum of the reference
+//               is exact, hence reference == E (B = 0).  Beyond: B = n * 2^-53 * E (n addends).
+//   float64 AF: E sums the float32-rounded values exactly: B = (2^-24 + n * 2^-53) * E.
+// k_cand keeps the samples whose weighted interval reaches the best lower bound -- only they can be
+// the argmax -- and k_chain recomputes exactly those few with the reference's sequential chain.
+// Result: bit-identical winner and score, with the bulk of the work order independent.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c, double &lo, double &hi, double &est,
+                                            bool &exact)
+{
+    const i64 e = a.afsum[s];
+    est = (double)e * a.af_scale;
+    double bound;
+    if (a.af_is_f64) {
+        exact = c == 0;
+        bound = exact ? 0.0 : 1.02 * (5.9604644775390625e-08 + (double)c * 1.1102230246251565e-16) * est;
+    } else {
+        exact = e < (1ll << 53);
+        bound = exact ? 0.0 : 1.05 * ((double)c * 1.1102230246251565e-16 * est + 1.2e-16 * est);
+    }
+    double l = est - bound, h = est + bound;
+    if (l < 0.0) l = 0.0;
+    if (a.weights) {
+        const double w = a.weights[a.first + s];
+        l *= w;  // rounding is monotone: fl(R*w) lies between fl(l*w) and fl(h*w)
+        h *= w;
+        if (w < 0.0) { const double t = l; l = h; h = t; }
+    }
+    lo = l;
+    hi = h;
+}
+
+__global__ __launch_bounds__(256) void k_cand(PickArgs a)
+{
+    __shared__ double wmax[4];
+    __shared__ unsigned n_c;
+    __shared__ int inexact;
+    IterState *st = a.st;
+    if (st->done) return;
+    const unsigned n_active = st->n_active;
+    if (threadIdx.x == 0) { n_c = 0; inexact = 0; }
+    double best_lo = -__builtin_inf();
+    for (unsigned i = threadIdx.x; i < n_active; i += 256) {
+        const unsigned s = a.act[i];
+        double lo, hi, est;
+        bool exact;
+        af_interval(a, s, a.cnt[s], lo, hi, est, exact);
+        best_lo = lo > best_lo ? lo : best_lo;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(best_lo, o, 64);
+        best_lo = other > best_lo ? other : best_lo;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best_lo;
+    __syncthreads();
+    best_lo = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    for (unsigned i = threadIdx.x; i < n_active; i += 256) {
+        const unsigned s = a.act[i];
+        const u64 c = a.cnt[s];
+        double lo, hi, est;
+        bool exact;
+        af_interval(a, s, c, lo, hi, est, exact);
+        if (hi >= best_lo) {
+            const unsigned slot = atomicAdd(&n_c, 1u);
+            if (slot < UTM_MAX_CAND) {
+                a.cand->pos[slot] = i;
+                a.cand->samp[slot] = s;
+                a.cand->cnt[slot] = (i64)c;
+                a.cand->val[slot] = est;
+            }
+            if (!exact) inexact = 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->n_cand = n_c < UTM_MAX_CAND ? (int)n_c : UTM_MAX_CAND;
+        st->cand_overflow = n_c > UTM_MAX_CAND;
+        st->need_chain = inexact;
+    }
+}
+
+
+// The reference's chain for ONE candidate per workgroup: 1024 lanes compact the AF values of the
+// candidate's surviving bits, in ascending variant order, into LDS (popcount -> block prefix sum ->
+// scatter); lane 0 then adds them one by one in float64.  Only the additions are serial.
+#define UTM_CHAIN_CAP 2048
+template <typename AF_T>
+__global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chunks, int n_chunks,
+                                                const IterState *__restrict__ st, CandBuf *__restrict__ cand)
+{
+    __shared__ double buf[UTM_CHAIN_CAP];
+    __shared__ unsigned wtot[16];
+    if (st->done || !st->need_chain || st->cand_overflow || (int)blockIdx.x >= st->n_cand) return;
+    const unsigned s = cand->samp[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc = 0.0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const SeqChunk ch = chunks[c];
+        const u64 *col = ch.cols + (u64)s * ch.wp;
+        const AF_T *af = static_cast<const AF_T *>(ch.af);
+        u64 x_next = (u64)tid < ch.w ? (col[tid] & ~ch.covered[tid]) : 0;
+        for (u64 w0 = 0; w0 < ch.w; w0 += 1024) {
+            const u64 w = w0 + tid;
+            const u64 x = x_next;
+            const u64 wn = w + 1024;
+            x_next = wn < ch.w ? (col[wn] & ~ch.covered[wn]) : 0;  // in flight during this round
+            const unsigned n = __popcll(x);
+            const unsigned incl = wave_scan_incl_u32(n);
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            unsigned woff = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned t = wtot[k];
+                woff += k < wave ? t : 0;
+                total += t;
+            }
+            if (total == 0) {
+                __syncthreads();
+                continue;
+            }
+            const unsigned off = woff + incl - n;
+            for (unsigned base = 0; base < total; base += UTM_CHAIN_CAP) {
+                u64 y = x;
+                unsigned p = off;
+                while (y) {
+                    const int b = __builtin_ctzll(y);
+                    y &= y - 1;
+                    if (p >= base && p < base + UTM_CHAIN_CAP) buf[p - base] = (double)af[w * 64 + b];
+                    ++p;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    const unsigned m = total - base < UTM_CHAIN_CAP ? total - base : UTM_CHAIN_CAP;
+                    for (unsigned t = 0; t < m; ++t) acc += buf[t];
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (tid == 0) cand->val[blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: mask / weight / argmax (select.py:43-53) over the selectable local samples and, when this is
 // the only shard, the decision and bookkeeping of greedy_select (select.py:93-112).  One workgroup.
 // ------------------------------------------------------------------------------------------------
-struct Cand {
-    double val;
-    i64 gidx;
-    i64 cnt;
-    unsigned pos;
-};
 __device__ __forceinline__ bool better(const Cand &a, const Cand &b)
 {  // np.argmax: highest score, first (lowest) index on ties
     return a.val > b.val || (a.val == b.val && a.gidx < b.gidx);
@@ -305,29 +505,7 @@ __device__ __forceinline__ Cand shfl_cand(const Cand &c, int o)
     return r;
 }
 
-struct PickArgs {
-    IterState *st;
-    unsigned *act;
-    unsigned char *state;
-    const double *weights;  // n_samp_total, or nullptr
-    u64 *cnt;
-    i64 *afsum;      // fixed-point AF sums, or nullptr
-    double *fscore;  // sequential AF scores, or nullptr
-    double af_scale; // 2^-q
-    Rec *recs;       // exchange slot headers: recs[r] at xbuf + r*slot_words
-    u64 slot_words;
-    i64 *res_idx;
-    i64 *res_new;
-    double *res_score;
-    i64 n_var_total;
-    unsigned first, n_local, n_total;
-    int rank, n_ranks;
-};
 
-__device__ __forceinline__ Rec *rec_of(const PickArgs &a, int r)
-{
-    return reinterpret_cast<Rec *>(reinterpret_cast<u64 *>(a.recs) + (u64)r * a.slot_words);
-}
 
 // Runs in ONE thread.  Same inputs on every shard => same decision on every shard.
 __device__ void decide(const PickArgs &a)
@@ -378,21 +556,34 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs a)
     IterState *st = a.st;
     if (st->done) return;
     const unsigned n_active = st->n_active;
+    // where this iteration's scores come from
+    //   0 integer counts | 1 exact fixed-point AF sums | 2 sequential float64 scores of every sample
+    //   3 the candidates' sequential float64 scores (k_chain)
+    int src = a.afsum ? 1 : a.fscore ? 2 : 0;
+    if (a.cand && st->need_chain) src = st->cand_overflow ? 2 : 3;
     Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+    if (src == 3) {
+        const unsigned n_cand = (unsigned)st->n_cand;
+        for (unsigned b = threadIdx.x; b < n_cand; b += 256) {
+            const unsigned s = a.cand->samp[b];
+            double v = a.cand->val[b];
+            if (a.weights) v *= a.weights[a.first + s];
+            const Cand cand{v, (i64)a.first + s, a.cand->cnt[b], a.cand->pos[b]};
+            if (better(cand, best)) best = cand;
+        }
+    }
     for (unsigned i = threadIdx.x; i < n_active; i += 256) {
         const unsigned s = a.act[i];
         const u64 c = a.cnt[s];
         a.cnt[s] = 0;  // ready for the next iteration's atomics
-        double v;
+        double v = (double)c;
         if (a.afsum) {
             const i64 q = a.afsum[s];
             a.afsum[s] = 0;
-            v = (double)q * a.af_scale;  // exact: |q| < 2^53 and the scale is a power of two
-        } else if (a.fscore) {
-            v = a.fscore[s];
-        } else {
-            v = (double)c;
+            v = (double)q * a.af_scale;  // exact: q < 2^53 whenever this value is used, and the scale is a power of two
         }
+        if (src == 3) continue;
+        if (src == 2) v = a.fscore[s];
         if (a.weights) v *= a.weights[a.first + s];
         const Cand cand{v, (i64)a.first + s, (i64)c, i};
         if (better(cand, best)) best = cand;

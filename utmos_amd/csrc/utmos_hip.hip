@@ -97,8 +97,8 @@ struct Chunk {
     u64 off = 0; // word offset of this chunk inside a whole-column buffer
     u64 *cols = nullptr;
     u64 *covered = nullptr;
-    void *af = nullptr;   // device: float or double per variant (sequential modes)
-    i64 *afq = nullptr;   // device: fixed-point AF, wp*64 entries
+    void *af = nullptr;    // device: AF in its own type (float or double), wp*64 entries: chains read this
+    float *af32 = nullptr; // device: float32 AF for the parallel estimate (== af when the AF is float32)
     std::vector<float> h_af32;
     std::vector<double> h_af64;
 };
@@ -127,13 +127,14 @@ struct utm_ctx {
     int xbuf_ranks = 0;
     u64 xbuf_slot_words = UTM_HDR_WORDS;  // slot size the buffer was allocated for
     SeqChunk *d_seq = nullptr;
+    CandBuf *d_cand = nullptr;
     u64 *d_varcount = nullptr;
     bool varcount_valid = false;
 
     std::vector<unsigned char> h_state;  // n_total, as last set (initial states)
     bool have_weights = false;
     int af_mode = UTM_AF_NONE;
-    bool af_fixed = false;
+    bool af_fixed = false;  // AF runs as the verified-parallel scheme (exact fixed-point estimate + chains)
     int af_q = 0;
     bool prepared = false;  // device loop state matches h_state / AF tables
     bool dirty_tables = true;
@@ -191,6 +192,7 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     HIP_TRY(hipMalloc(&c->d_res_new, ((size_t)n_samp_total + 1) * 8));
     HIP_TRY(hipMalloc(&c->d_res_score, ((size_t)n_samp_total + 1) * 8));
     HIP_TRY(hipMalloc(&c->d_xbuf, UTM_HDR_WORDS * 8));
+    HIP_TRY(hipMalloc(&c->d_cand, sizeof(CandBuf)));
     c->xbuf_ranks = 1;
     HIP_TRY(hipEventCreate(&c->ev_loop0));
     HIP_TRY(hipEventCreate(&c->ev_loop1));
@@ -206,9 +208,10 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     for (auto &ch : c->chunks) {
         (void)hipFree(ch.cols);
         (void)hipFree(ch.covered);
+        if ((void *)ch.af32 != ch.af) (void)hipFree(ch.af32);
         (void)hipFree(ch.af);
-        (void)hipFree(ch.afq);
     }
+    (void)hipFree(c->d_cand);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
     (void)hipFree(c->d_xbuf); (void)hipFree(c->d_seq); (void)hipFree(c->d_varcount);
@@ -468,60 +471,71 @@ extern "C" int utm_set_af(utm_ctx *c, int32_t chunk, int mode, const void *af)
     return UTM_OK;
 }
 
-// Decide the AF arithmetic and build the device tables (SURVEY.md §8a-AF).
+// Decide the AF arithmetic and build the device tables (SURVEY.md §8a-AF, DESIGN.md §4).
 static int build_af_tables(utm_ctx *c)
 {
     if (!c->dirty_tables) return UTM_OK;
     for (auto &ch : c->chunks) {
-        (void)hipFree(ch.af); ch.af = nullptr;
-        (void)hipFree(ch.afq); ch.afq = nullptr;
+        if ((void *)ch.af32 != ch.af) (void)hipFree(ch.af32);
+        (void)hipFree(ch.af);
+        ch.af = nullptr;
+        ch.af32 = nullptr;
     }
-    (void)hipFree(c->d_seq); c->d_seq = nullptr;
+    (void)hipFree(c->d_seq);
+    c->d_seq = nullptr;
     c->af_fixed = false;
     c->af_q = 0;
     if (c->af_mode == UTM_AF_NONE) { c->dirty_tables = false; return UTM_OK; }
     for (auto &ch : c->chunks)
         if ((c->af_mode == UTM_AF_F32 ? ch.h_af32.size() : ch.h_af64.size()) != ch.n_var)
             return fail(UTM_ESTATE, "AF not set for every chunk");
-    if (c->af_mode == UTM_AF_F32 && !(c->flags & UTM_FLAG_AF_SEQUENTIAL)) {
-        // Every float32 a > 0 is m * 2^(e-23) with integer m < 2^24, i.e. a multiple of 2^-q for
-        // q = 23 - e_min.  If the total AF mass stays below 2^(53-q) every partial sum of the
-        // reference's float64 accumulation is exact, so the sum is order independent and equals
-        // (sum of a*2^q as int64) / 2^q bit for bit.
-        int e_min = 1000;
-        long double mass = 0;
-        for (auto &ch : c->chunks)
-            for (float a : ch.h_af32) {
-                if (a == 0.0f) continue;
-                int e;
-                frexpf(a, &e);  // a = f * 2^e, f in [0.5,1): exponent of the leading bit is e-1
-                const int lead = fpclassify(a) == FP_SUBNORMAL ? -126 : e - 1;
-                e_min = std::min(e_min, lead);
-                mass += a;
-            }
-        if (e_min == 1000) e_min = 0;
-        const int q = 23 - e_min;
-        if (q <= 60 && q >= 0 && mass < ldexpl(1.0L, 53 - q) * 0.999L) {
-            c->af_fixed = true;
-            c->af_q = q;
+    // float32 view of the AF values: the data itself (F32) or its rounding (F64, estimate only)
+    std::vector<std::vector<float>> v32(c->chunks.size());
+    bool representable = true;
+    int e_min = 1000, e_max = -1000;
+    long double mass = 0;
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        Chunk &ch = c->chunks[k];
+        v32[k].assign(ch.wp * 64, 0.0f);
+        for (u64 v = 0; v < ch.n_var; ++v) {
+            const float a = c->af_mode == UTM_AF_F32 ? ch.h_af32[v] : (float)ch.h_af64[v];
+            v32[k][v] = a;
+            if (c->af_mode == UTM_AF_F64 && ch.h_af64[v] != 0.0 && (!(a > 0.0f) || !isfinite(a))) representable = false;
+            if (a == 0.0f) continue;
+            if (fpclassify(a) == FP_SUBNORMAL) { representable = false; continue; }
+            int e;
+            frexpf(a, &e);  // a = f * 2^e, f in [0.5, 1): the leading bit has weight 2^(e-1)
+            e_min = std::min(e_min, e - 1);
+            e_max = std::max(e_max, e - 1);
+            mass += a;
         }
     }
-    {
-        std::vector<SeqChunk> seq;
-        for (auto &ch : c->chunks) {
-            const size_t esz = c->af_mode == UTM_AF_F32 ? 4 : 8;
-            const size_t n = ch.wp * 64;
-            HIP_TRY(hipMalloc(&ch.af, n * esz));
-            HIP_TRY(hipMemset(ch.af, 0, n * esz));
-            HIP_TRY(hipMemcpy(ch.af, c->af_mode == UTM_AF_F32 ? (const void *)ch.h_af32.data() : (const void *)ch.h_af64.data(),
-                              ch.n_var * esz, hipMemcpyHostToDevice));
-            seq.push_back(SeqChunk{ch.cols, ch.covered, ch.af, ch.wp, ch.w});
-        }
-        if (!c->af_fixed) {
-            HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
-            HIP_TRY(hipMemcpy(c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
-        }
+    if (e_min == 1000) e_min = e_max = 0;
+    // Every float32 a > 0 is m * 2^(e-23), m < 2^24: a multiple of 2^-q for q = 23 - e_min.  The
+    // estimate kernel sums a * 2^q = m << (e - e_min) as int64: needs q >= 0 and mass * 2^q < 2^62.
+    const int q = 23 - e_min;
+    if (!(c->flags & UTM_FLAG_AF_SEQUENTIAL) && representable && q >= 0 && q <= 149 &&
+        e_max - e_min <= 38 && mass * ldexpl(1.0L, q - 62) < 1.0L) {
+        c->af_fixed = true;
+        c->af_q = q;
     }
+    std::vector<SeqChunk> seq;
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        Chunk &ch = c->chunks[k];
+        const size_t n = ch.wp * 64;
+        HIP_TRY(hipMalloc(&ch.af32, n * 4));
+        HIP_TRY(hipMemcpy(ch.af32, v32[k].data(), n * 4, hipMemcpyHostToDevice));
+        if (c->af_mode == UTM_AF_F32) {
+            ch.af = ch.af32;
+        } else {
+            HIP_TRY(hipMalloc(&ch.af, n * 8));
+            HIP_TRY(hipMemset(ch.af, 0, n * 8));
+            HIP_TRY(hipMemcpy(ch.af, ch.h_af64.data(), ch.n_var * 8, hipMemcpyHostToDevice));
+        }
+        seq.push_back(SeqChunk{ch.cols, ch.covered, ch.af, ch.wp, ch.w});
+    }
+    HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
+    HIP_TRY(hipMemcpy(c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
     c->dirty_tables = false;
     return UTM_OK;
 }
@@ -599,8 +613,10 @@ static PickArgs pick_args(utm_ctx *c)
     a.weights = c->have_weights ? c->d_weights : nullptr;
     a.cnt = c->d_cnt;
     a.afsum = (c->af_mode != UTM_AF_NONE && c->af_fixed) ? c->d_afsum : nullptr;
-    a.fscore = (c->af_mode != UTM_AF_NONE && !c->af_fixed) ? c->d_fscore : nullptr;
+    a.fscore = c->af_mode != UTM_AF_NONE ? c->d_fscore : nullptr;  // sequential scores (fallback / overflow)
     a.af_scale = ldexp(1.0, -c->af_q);
+    a.cand = (c->af_mode != UTM_AF_NONE && c->af_fixed) ? c->d_cand : nullptr;
+    a.af_is_f64 = c->af_mode == UTM_AF_F64;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
     a.slot_words = c->xbuf_slot_words;
     a.res_idx = c->d_res_idx;
@@ -635,7 +651,7 @@ static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsig
 }
 
 // Enqueue the scoring of one iteration for every chunk (and the pending covered update).
-static int enqueue_score(utm_ctx *c)
+static int enqueue_score(utm_ctx *c, bool force_sequential = false)
 {
     const unsigned a_ub = std::max(1u, c->active_ub);
     const u64 slot = c->xbuf_slot_words;
@@ -658,7 +674,7 @@ static int enqueue_score(utm_ctx *c)
         (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
         c->ev_used += 2;
     };
-    if (c->af_mode != UTM_AF_NONE && !c->af_fixed) {
+    if (c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential)) {
         // sequential chain: update covered first, then one lane per sample over all chunks
         for (auto &ch : c->chunks)
             hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
@@ -667,10 +683,10 @@ static int enqueue_score(utm_ctx *c)
         const unsigned blocks = (a_ub + 63) / 64;
         if (c->af_mode == UTM_AF_F32)
             hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                               c->d_act, c->d_cnt, c->d_fscore);
+                               c->d_act, c->d_cnt, c->d_fscore, 0);
         else
             hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                               c->d_act, c->d_cnt, c->d_fscore);
+                               c->d_act, c->d_cnt, c->d_fscore, 0);
         ev_end();
         c->score_launches += 1;
     } else {
@@ -685,7 +701,7 @@ static int enqueue_score(utm_ctx *c)
                 unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
                 n_groups = (a_ub + group - 1) / group;
                 hipLaunchKernelGGL(k_score_afq, dim3((unsigned)(tiles * n_groups)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                                   static_cast<const float *>(ch.af), 150 - c->af_q, c->d_xbuf, slot, ch.off, c->d_st, c->d_act,
+                                   ch.af32, 150 - c->af_q, c->d_xbuf, slot, ch.off, c->d_st, c->d_act,
                                    c->d_cnt, c->d_afsum, group, n_groups);
             } else {
                 const u64 steps_total = ch.wp / UTM_STEP_WORDS;
@@ -729,6 +745,20 @@ static i64 iteration_bytes(const utm_ctx *c, u64 a)
 static int enqueue_pick_and_exchange(utm_ctx *c)
 {
     PickArgs a = pick_args(c);
+    if (a.cand) {
+        // verified-parallel AF: candidates -> their sequential chains (-> everyone, if too many tie)
+        hipLaunchKernelGGL(k_cand, dim3(1), dim3(256), 0, c->stream, a);
+        const unsigned blocks = (std::max(1u, c->active_ub) + 63) / 64;
+        if (c->af_mode == UTM_AF_F32) {
+            hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand);
+            hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                               c->d_act, c->d_cnt, c->d_fscore, 1);
+        } else {
+            hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand);
+            hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                               c->d_act, c->d_cnt, c->d_fscore, 1);
+        }
+    }
     if (!c->comm) {
         hipLaunchKernelGGL(k_pick<true>, dim3(1), dim3(256), 0, c->stream, a);
     } else {
@@ -792,11 +822,15 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         enq += n;
         const i64 before = c->iter;
         TRY(sync_state(c));
-        // bytes: iterations that were actually scored in this batch (rows + a terminating empty pass)
+        // bytes: iterations that were actually scored in this batch (rows + a terminating empty pass); the
+        // local selectable count falls from a0 to a1 over the batch's rows (by one per row on a single shard)
         const i64 rows = c->iter - before;
         const i64 passes = std::min<i64>(n, rows + ((c->finished && c->h_st->tot < (i64)c->n_var_total && rows < n) ? 1 : 0));
-        for (i64 j = 0; j < passes; ++j)
-            c->algo_bytes += iteration_bytes(c, c->n_ranks == 1 ? (a0 > (u64)j ? a0 - j : 0) : a0);
+        const unsigned a1 = c->active_ub;
+        for (i64 j = 0; j < passes; ++j) {
+            const u64 drop = rows > 0 ? (u64)(a0 - a1) * (u64)std::min(j, rows) / (u64)rows : 0;
+            c->algo_bytes += iteration_bytes(c, a0 - drop);
+        }
         c->scored += passes;
         if (c->flags & UTM_FLAG_PROFILE_EVENTS) TRY(collect_event_times(c));
     }
@@ -833,12 +867,15 @@ extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
 {
     CTX(c);
     TRY(ensure_prepared(c));
-    TRY(enqueue_score(c));
+    // with AF every sample's exact reference score is wanted, so all of them take the sequential chain
+    TRY(enqueue_score(c, /*force_sequential=*/true));
     i64 *d_counts = nullptr;
     double *d_scores = nullptr;
     HIP_TRY(hipMalloc(&d_counts, (size_t)c->n_local * 8));
     HIP_TRY(hipMalloc(&d_scores, (size_t)c->n_local * 8));
-    hipLaunchKernelGGL(k_final_scores, dim3((c->n_local + 255) / 256), dim3(256), 0, c->stream, pick_args(c), d_counts, d_scores);
+    PickArgs pa = pick_args(c);
+    pa.afsum = nullptr;
+    hipLaunchKernelGGL(k_final_scores, dim3((c->n_local + 255) / 256), dim3(256), 0, c->stream, pa, d_counts, d_scores);
     (void)hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream);
     (void)hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
