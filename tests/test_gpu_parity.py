@@ -151,6 +151,19 @@ def test_af_modes(dev, mode):
     check_run(dev, dense, af=af, weights=w, af_sequential=(mode == "f32_seq"), k=40)
 
 
+@pytest.mark.parametrize("switch", ["0", "2"])
+def test_af_dense_and_sparse_kernels_agree(dev, switch, monkeypatch):
+    """UTM_AF_SWITCH=0 runs every iteration on the sparse-phase kernel (global AF gathers), 2 keeps the
+    LDS-tile kernel throughout; both must give the oracle's rows."""
+    monkeypatch.setenv("UTM_AF_SWITCH", switch)
+    rng = np.random.default_rng(18)
+    n_var, n_samp = 64 * 128 * 9 + 321, 70
+    dense = ou.random_dense(rng, n_var, n_samp)
+    af = (dense.sum(axis=1) / (2.0 * n_samp)).astype(np.float32)
+    check_run(dev, dense, af=af)
+    check_run(dev, dense, af=af.astype(np.float64) / 3.0, chunks=[0, 8192 * 3, n_var])
+
+
 def test_af_f32_falls_back_when_not_representable(dev):
     rng = np.random.default_rng(10)
     dense = ou.random_dense(rng, 2000, 50)
@@ -258,16 +271,18 @@ def test_sharded_building_blocks_two_shards_one_gpu(dev):
     w = rng.choice([1.0, 2.0], n_samp)
     state = np.ones(n_samp, np.uint8)
     state[7] = 2
-    exp = ou.c_greedy(cols, n_var, state, w)
+    af = dense.sum(axis=1) / (2.0 * n_samp) / 3.0        # float64 AF: every local best needs its chain
+    exp = ou.c_greedy(cols, n_var, state, w, af=af)
     shards = []
     for first, n in ((0, 21), (21, 29)):
         m = dev.DeviceMatrix(n_samp, first_sample=first, n_local=n)
         c = m.add_chunk(n_var)
         m.upload_columns(c, cols[first:first + n])
+        m.set_af(c, af)
         m.set_state(state)
         m.set_weights(w)
         shards.append(m)
-    got_idx, got_new = [], []
+    got_idx, got_new, got_score = [], [], []
     for _ in range(n_samp):
         recs = [m.local_best() for m in shards]
         cand = [(-r[0], r[1], i) for i, r in enumerate(recs) if r[1] >= 0]
@@ -281,9 +296,10 @@ def test_sharded_building_blocks_two_shards_one_gpu(dev):
             break
         got_idx.append(outs[0][0])
         got_new.append(outs[0][1])
+        got_score.append(outs[0][2])
     for m in shards:
         m.close()
-    assert got_idx == exp[0].tolist() and got_new == exp[1].tolist()
+    assert got_idx == exp[0].tolist() and got_new == exp[1].tolist() and got_score == exp[2].tolist()
 
 
 def test_rccl_single_rank_path(dev):

@@ -32,6 +32,7 @@ struct IterState {
     int n_cand;         // candidates whose score interval reaches the best lower bound
     int need_chain;     // some candidate's parallel sum is not provably the reference's float64 sum
     int cand_overflow;  // more candidates than UTM_MAX_CAND: every sample is re-scored sequentially
+    int all_exact;      // every selectable sample's estimate is exact; scores only shrink, so it stays that way
 };
 
 #define UTM_MAX_CAND 64
@@ -286,6 +287,127 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1-AF, sparse phase: once a good part of the variants is covered most loaded words are zero after
+// the AND, so this kernel is k_score_int's streaming loop (LDS-staged ~covered tile, 8 KiB in flight
+// per wave) plus a per-wave LDS queue: surviving bits only *enqueue* their variant index (prefix sum
+// over the lanes, no memory wait); when the queue fills up, and at the end of the (sample, tile), all
+// 64 lanes drain it together -- independent float32 gathers from the AF table in global memory (it
+// stays in L2 / Infinity Cache), mantissa << exponent, 64-bit add -- then ONE reduction per (sample,
+// tile).  The host switches from k_score_afq to this kernel when the captured fraction passes
+// UTM_AF_SWITCH.  Same integer sums, same exactness argument.
+// ------------------------------------------------------------------------------------------------
+#define UTM_AFQ_CAP 1024  // queue entries per wave
+__device__ __forceinline__ u64 af_fixed(unsigned f, int e_base)
+{
+    return (u64)((f & 0x7FFFFFu) | 0x800000u) << ((f >> 23) - e_base);
+}
+
+template <int STEPS>
+__global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+                                                   const unsigned *__restrict__ afbits, int e_base,
+                                                   const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                                   const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                   u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
+                                                   unsigned n_groups)
+{
+    __shared__ v4u live[STEPS * 64];
+    __shared__ unsigned queue[4][UTM_AFQ_CAP];
+    if (st->done) return;
+    const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
+    const u64 left = (wp - w0) / UTM_STEP_WORDS;
+    const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
+    v4u *cv = reinterpret_cast<v4u *>(covered + w0);
+    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
+    for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
+        v4u c = cv[i];
+        if (wc) {
+            c |= wc[i];
+            if (grp == 0) cv[i] = c;
+        }
+        live[i] = ~c;
+    }
+    __syncthreads();
+
+    const unsigned n_active = st->n_active;
+    const unsigned lo = grp * group_size;
+    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int U = STEPS < 8 ? STEPS : 8;
+    unsigned *q = queue[wave];
+    const unsigned *af_tile = afbits + w0 * 64;  // AF of the tile's first variant
+    for (unsigned i = lo + wave; i < hi; i += 4) {
+        const unsigned s = act[i];
+        const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
+        unsigned acc = 0, qn = 0;  // qn is wave uniform
+        u64 sum = 0;
+        auto drain = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (unsigned e = lane; e < qn; e += 64) sum += af_fixed(af_tile[q[e]], e_base);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            qn = 0;
+        };
+        for (int j0 = 0; j0 < nsteps; j0 += U) {
+            v4u b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                b[u] = j0 + u < nsteps ? __builtin_nontemporal_load(p + (j0 + u) * 64) : (v4u)(0);
+            unsigned nb = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j0 + u < nsteps) b[u] &= live[(j0 + u) * 64 + lane];
+                nb += __popc(b[u].x) + __popc(b[u].y) + __popc(b[u].z) + __popc(b[u].w);
+            }
+            acc += nb;
+            if (__ballot(nb != 0) == 0) continue;  // nothing survived in these 8 KiB
+            const unsigned incl = wave_scan_incl_u32(nb);
+            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            if (qn + total > UTM_AFQ_CAP) drain();
+            const unsigned base = (unsigned)(j0 * UTM_STEP_WORDS + 2 * lane) * 64;  // variant offset inside the tile
+            if (total <= UTM_AFQ_CAP) {
+                unsigned pos = qn + incl - nb;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned bits = b[u][d];
+                        const unsigned v0 = base + u * (UTM_STEP_WORDS * 64) + d * 32;
+                        while (bits) {
+                            q[pos++] = v0 + __builtin_ctz(bits);
+                            bits &= bits - 1;
+                        }
+                    }
+                }
+                qn += total;
+            } else {  // dense data: more bits in one batch than the queue holds -- gather them directly
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned bits = b[u][d];
+                        const unsigned v0 = base + u * (UTM_STEP_WORDS * 64) + d * 32;
+                        while (bits) {
+                            sum += af_fixed(af_tile[v0 + __builtin_ctz(bits)], e_base);
+                            bits &= bits - 1;
+                        }
+                    }
+                }
+            }
+        }
+        if (qn) drain();
+        const unsigned n = wave_sum_u32(acc);
+        if (n) {  // wave uniform
+            const i64 total = wave_sum_u63(sum);
+            if (lane == 0) {
+                atomicAdd(&cnt[s], (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), (u64)total);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sequential AF (float64 AF, or float32 AF that fails the fixed-point precondition): the reference
 // adds row values into a float64 score in ascending variant order (`scores += row`, select.py:40);
 // float64 addition does not reassociate, so each sample's chain is walked by ONE lane, chunk after
@@ -379,11 +501,11 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
 {
     __shared__ double wmax[4];
     __shared__ unsigned n_c;
-    __shared__ int inexact;
+    __shared__ int inexact, any_inexact;
     IterState *st = a.st;
     if (st->done) return;
     const unsigned n_active = st->n_active;
-    if (threadIdx.x == 0) { n_c = 0; inexact = 0; }
+    if (threadIdx.x == 0) { n_c = 0; inexact = 0; any_inexact = 0; }
     double best_lo = -__builtin_inf();
     for (unsigned i = threadIdx.x; i < n_active; i += 256) {
         const unsigned s = a.act[i];
@@ -406,6 +528,7 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
         double lo, hi, est;
         bool exact;
         af_interval(a, s, c, lo, hi, est, exact);
+        if (!exact) any_inexact = 1;
         if (hi >= best_lo) {
             const unsigned slot = atomicAdd(&n_c, 1u);
             if (slot < UTM_MAX_CAND) {
@@ -422,6 +545,7 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
         st->n_cand = n_c < UTM_MAX_CAND ? (int)n_c : UTM_MAX_CAND;
         st->cand_overflow = n_c > UTM_MAX_CAND;
         st->need_chain = inexact;
+        st->all_exact = !any_inexact;
     }
 }
 

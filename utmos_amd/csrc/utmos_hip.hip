@@ -143,6 +143,8 @@ struct utm_ctx {
     i64 iter = 0;             // rows produced
     i64 scored = 0;           // scoring passes run (>= iter)
     unsigned active_ub = 0;   // upper bound of local selectable samples (exact while the loop is alive)
+    i64 captured_seen = 0;    // tot_captured as of the last sync
+    bool af_all_exact = false; // latched from the device: AF estimates are exact from here on (no candidates needed)
     bool finished = false;
 
     // RCCL
@@ -587,6 +589,8 @@ extern "C" int utm_reset(utm_ctx *c)
     HIP_TRY(hipMemcpyAsync(c->d_st, &st, sizeof st, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->iter = 0;
+    c->captured_seen = 0;
+    c->af_all_exact = false;
     c->scored = 0;
     c->active_ub = (unsigned)act.size();
     c->finished = false;
@@ -615,7 +619,8 @@ static PickArgs pick_args(utm_ctx *c)
     a.afsum = (c->af_mode != UTM_AF_NONE && c->af_fixed) ? c->d_afsum : nullptr;
     a.fscore = c->af_mode != UTM_AF_NONE ? c->d_fscore : nullptr;  // sequential scores (fallback / overflow)
     a.af_scale = ldexp(1.0, -c->af_q);
-    a.cand = (c->af_mode != UTM_AF_NONE && c->af_fixed) ? c->d_cand : nullptr;
+    // float32 AF sums only shrink: once every estimate was exact (< 2^53 units) the plain exact pick suffices
+    a.cand = (c->af_mode != UTM_AF_NONE && c->af_fixed && !c->af_all_exact) ? c->d_cand : nullptr;
     a.af_is_f64 = c->af_mode == UTM_AF_F64;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
     a.slot_words = c->xbuf_slot_words;
@@ -660,6 +665,12 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
     static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
     static const int use_nt = tune_env("UTM_NT_LOADS", 1);
     const bool profile = c->flags & UTM_FLAG_PROFILE_EVENTS;
+    // AF: dense phase -> LDS-tile kernel, sparse phase -> streaming kernel with global AF gathers.  The
+    // captured fraction is known from the last batch sync (identical on every shard).
+    const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
+    const double af_switch = sw && *sw ? atof(sw) : 0.2;
+    const bool af_sparse = c->af_mode != UTM_AF_NONE && c->af_fixed && c->n_var_total > 0 &&
+                           (double)c->captured_seen >= af_switch * (double)c->n_var_total;
     auto ev_begin = [&]() {
         if (!profile) return;
         if (c->ev_used + 2 > c->ev.size()) {
@@ -692,9 +703,8 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
     } else {
         for (auto &ch : c->chunks) {
             ev_begin();
-            if (c->af_mode != UTM_AF_NONE) {
+            if (c->af_mode != UTM_AF_NONE && !af_sparse) {
                 const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
-                // few, large groups: every workgroup re-stages its 64 KiB AF tile
                 // every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache): groups of >= 64 samples
                 static const int af_target = tune_env("UTM_AF_TARGET_WGS", 16384);
                 unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)af_target / std::max<u64>(1, tiles)));
@@ -707,17 +717,28 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                 const u64 steps_total = ch.wp / UTM_STEP_WORDS;
                 const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
                 int steps = 2;
-                for (int cand : {32, 8}) {
+                const int big = c->af_mode != UTM_AF_NONE ? 16 : 32;  // the AF kernel shares LDS with its bit queues
+                for (int cand : {big, 8}) {
                     const u64 tiles = (steps_total + cand - 1) / cand;
                     if (tiles * waves_needed >= (u64)min_wgs) { steps = cand; break; }
                 }
-                if (force_steps == 32 || force_steps == 8 || force_steps == 2) steps = force_steps;
+                if (c->af_mode == UTM_AF_NONE && (force_steps == 32 || force_steps == 8 || force_steps == 2)) steps = force_steps;
                 const u64 tiles = (steps_total + steps - 1) / steps;
                 u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
                 group = std::max<u64>(4, (group + 3) / 4 * 4);
                 const unsigned n_groups = (unsigned)((a_ub + group - 1) / group);
                 const unsigned blocks = (unsigned)(tiles * n_groups);
-                if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+                if (c->af_mode != UTM_AF_NONE) {
+                    const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
+                    const int eb = 150 - c->af_q;
+#define UTM_LAUNCH_AFG(S)                                                                                              \
+    hipLaunchKernelGGL(k_score_afs<S>, dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb, c->d_xbuf, \
+                       slot, ch.off, c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups)
+                    if (steps == 16) UTM_LAUNCH_AFG(16);
+                    else if (steps == 8) UTM_LAUNCH_AFG(8);
+                    else UTM_LAUNCH_AFG(2);
+#undef UTM_LAUNCH_AFG
+                } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
                 else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
                 else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
             }
@@ -742,23 +763,27 @@ static i64 iteration_bytes(const utm_ctx *c, u64 a)
     return b;
 }
 
+// Verified-parallel AF: candidates -> their sequential chains (-> everyone, if too many tie).
+static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
+{
+    if (!a.cand) return;
+    hipLaunchKernelGGL(k_cand, dim3(1), dim3(256), 0, c->stream, a);
+    const unsigned blocks = (std::max(1u, c->active_ub) + 63) / 64;
+    if (c->af_mode == UTM_AF_F32) {
+        hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand);
+        hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                           c->d_act, c->d_cnt, c->d_fscore, 1);
+    } else {
+        hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand);
+        hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                           c->d_act, c->d_cnt, c->d_fscore, 1);
+    }
+}
+
 static int enqueue_pick_and_exchange(utm_ctx *c)
 {
     PickArgs a = pick_args(c);
-    if (a.cand) {
-        // verified-parallel AF: candidates -> their sequential chains (-> everyone, if too many tie)
-        hipLaunchKernelGGL(k_cand, dim3(1), dim3(256), 0, c->stream, a);
-        const unsigned blocks = (std::max(1u, c->active_ub) + 63) / 64;
-        if (c->af_mode == UTM_AF_F32) {
-            hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand);
-            hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                               c->d_act, c->d_cnt, c->d_fscore, 1);
-        } else {
-            hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand);
-            hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                               c->d_act, c->d_cnt, c->d_fscore, 1);
-        }
-    }
+    enqueue_candidates(c, a);
     if (!c->comm) {
         hipLaunchKernelGGL(k_pick<true>, dim3(1), dim3(256), 0, c->stream, a);
     } else {
@@ -782,6 +807,8 @@ static int sync_state(utm_ctx *c)
     HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->iter = c->h_st->iter;
+    c->captured_seen = c->h_st->tot;
+    if (c->h_st->all_exact) c->af_all_exact = true;
     c->active_ub = c->h_st->n_active;
     c->finished = c->h_st->done != 0;
     return UTM_OK;
@@ -812,7 +839,9 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     static const int batch = std::max(1, tune_env("UTM_BATCH", 64));
     i64 enq = 0;
     while (enq < k_max && !c->finished) {
-        const i64 n = std::min<i64>(batch, k_max - enq);
+        // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
+        const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, 8) : batch;
+        const i64 n = std::min<i64>(this_batch, k_max - enq);
         const unsigned a0 = c->active_ub;
         for (i64 j = 0; j < n; ++j) {
             TRY(enqueue_score(c));
@@ -955,6 +984,7 @@ extern "C" int utm_local_best(utm_ctx *c, utm_record *rec)
     if (c->finished) return UTM_OK;
     TRY(enqueue_score(c));
     PickArgs a = pick_args(c);
+    enqueue_candidates(c, a);
     hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(256), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     const u64 slot = c->xbuf_slot_words;
