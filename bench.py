@@ -178,11 +178,21 @@ def main():
             achieved = ps["algo_bytes"] / (ps["score_ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                        "kernel": "k_score_afq" if args.af else "k_score_int",
+                        "kernel": "k_score_afs (+k_score_afq for the first launches)" if args.af else "k_score_int",
                         "launches": ps["score_launches"],
                         "avg_launch_us": ps["score_ms"] * 1e3 / max(1, ps["score_launches"]),
                         "algo_bytes_per_launch": ps["algo_bytes"] / max(1, ps["score_launches"]),
                         "rank": rank}
+
+    # PMC traffic cannot be read from inside the process: report the recorded rocprofv3 --pmc passes of this
+    # same workload (tools/summarize_profile.py -> profiles/), when it is the default configuration
+    if roofline is not None and args.n_var == 10_000_000 and n_total == 2504 and args.select < 0 and world == 1 \
+            and not args.chunk_vars and (not args.af or args.af_dtype == "f32"):
+        rec = os.path.join(ROOT, "profiles", "r01_cfg3_pmc_hbm.json" if args.af else "r01_cfg2_pmc_hbm.json")
+        if os.path.exists(rec):
+            with open(rec) as fh:
+                roofline["traffic"] = json.load(fh)["hbm_bytes_per_launch_mean"]
+            roofline["traffic_source"] = os.path.relpath(rec, ROOT) + " (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
 
     cpu = bitset = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

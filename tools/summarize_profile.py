@@ -17,7 +17,7 @@ import sys
 
 def pmc_rows(d, prefix):
     f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
-    return [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(prefix)]
+    return [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(tuple(prefix.split(",")))]
 
 
 def main():

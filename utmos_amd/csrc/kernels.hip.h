@@ -674,9 +674,9 @@ __device__ void decide(const PickArgs &a)
 }
 
 template <bool DECIDE>
-__global__ __launch_bounds__(256) void k_pick(PickArgs a)
+__global__ __launch_bounds__(1024) void k_pick(PickArgs a)
 {
-    __shared__ Cand wbest[4];
+    __shared__ Cand wbest[16];
     IterState *st = a.st;
     if (st->done) return;
     const unsigned n_active = st->n_active;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs a)
     Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
     if (src == 3) {
         const unsigned n_cand = (unsigned)st->n_cand;
-        for (unsigned b = threadIdx.x; b < n_cand; b += 256) {
+        for (unsigned b = threadIdx.x; b < n_cand; b += 1024) {
             const unsigned s = a.cand->samp[b];
             double v = a.cand->val[b];
             if (a.weights) v *= a.weights[a.first + s];
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs a)
             if (better(cand, best)) best = cand;
         }
     }
-    for (unsigned i = threadIdx.x; i < n_active; i += 256) {
+    for (unsigned i = threadIdx.x; i < n_active; i += 1024) {
         const unsigned s = a.act[i];
         const u64 c = a.cnt[s];
         a.cnt[s] = 0;  // ready for the next iteration's atomics
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void k_pick(PickArgs a)
     if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < 16; ++w)
             if (better(wbest[w], best)) best = wbest[w];
         Rec *rc = rec_of(a, a.rank);
         rc->score = n_active ? best.val : 0.0;

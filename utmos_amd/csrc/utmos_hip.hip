@@ -785,9 +785,9 @@ static int enqueue_pick_and_exchange(utm_ctx *c)
     PickArgs a = pick_args(c);
     enqueue_candidates(c, a);
     if (!c->comm) {
-        hipLaunchKernelGGL(k_pick<true>, dim3(1), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_pick<true>, dim3(1), dim3(1024), 0, c->stream, a);
     } else {
-        hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(1024), 0, c->stream, a);
         u64 *slot = c->d_xbuf + (u64)c->rank * c->xbuf_slot_words;
         for (auto &ch : c->chunks)
             hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
@@ -985,7 +985,7 @@ extern "C" int utm_local_best(utm_ctx *c, utm_record *rec)
     TRY(enqueue_score(c));
     PickArgs a = pick_args(c);
     enqueue_candidates(c, a);
-    hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(1024), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     const u64 slot = c->xbuf_slot_words;
     HIP_TRY(hipMemcpyAsync(rec, c->d_xbuf + (u64)c->rank * slot, sizeof *rec, hipMemcpyDeviceToHost, c->stream));
