@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
     p.add_argument("--no-roofline-pass", action="store_true")
+    p.add_argument("--decremental", action="store_true",
+                   help="SURVEY 8f-4 shortcut (exact, reads far fewer bytes): reported separately, never the default")
     p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the exchange path)")
     return p.parse_args()
 
@@ -146,6 +148,8 @@ def main():
         uid, id_path = rendezvous_id(rank, world, device.DeviceMatrix.comm_unique_id)
         m.comm_init(rank, world, uid)
     k_sel = n_total if args.select < 0 else min(args.select, n_total)
+    if args.decremental:
+        m.set_decremental(True)
 
     def one_step():
         m.reset()
@@ -168,7 +172,7 @@ def main():
     tot_captured = st["tot_captured"]
 
     roofline = None
-    if not args.no_roofline_pass:
+    if not args.no_roofline_pass and not args.decremental:   # the roofline object describes the brute-force kernel only
         # same step once more with every scoring launch bracketed by HIP events on its own stream
         m.set_profile(True)
         one_step()
@@ -219,6 +223,10 @@ def main():
                    "tot_captured": tot_captured, "chunks": st["n_chunks"], "seed": args.seed,
                    "sharding": f"sample axis over {world} GPU(s), one ncclAllGather per iteration" if world > 1 else "none",
                    "generator_s": round(t_gen, 3), "af_verified_parallel": st["af_fixed_point"] if args.af else None},
+        "scoring": "decremental after the first passes (bytes = what this variant actually reads; NOT the brute-force "
+                   "roofline metric)" if args.decremental else "brute force: every selectable column re-read every iteration",
+        "decremental_iterations_per_step": st["decr_iterations"] if args.decremental else 0,
+        "brute_force_equivalent_gbps": st["brute_force_bytes"] * world * args.steps / elapsed / 1e9,
         "hbm_gbps_whole_loop": whole_loop_gbps, "hbm_frac_whole_loop": whole_loop_gbps / (HBM_PEAK_GBPS * world),
         "device_loop_ms_per_step": loop_ms / max(1, args.steps),
         "roofline": roofline, "cpu_baseline": cpu, "cpu_bitset_baseline": bitset,

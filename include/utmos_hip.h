@@ -52,6 +52,7 @@ typedef struct utm_ctx utm_ctx;
 /* utm_ctx_create flags */
 #define UTM_FLAG_PROFILE_EVENTS 1u /* bracket every scoring launch with HIP events (utm_stats.score_ms) */
 #define UTM_FLAG_AF_SEQUENTIAL 2u  /* never use the order-independent fixed-point form for F32 AF */
+#define UTM_FLAG_DECREMENTAL 4u    /* allow decremental scoring (utm_set_decremental) */
 
 /* One local-best record, as exchanged between shards (64 bytes). */
 typedef struct utm_record {
@@ -72,6 +73,8 @@ typedef struct utm_stats {
     int32_t af_fixed_point;  /* 1 when F32 AF runs as exact int64 fixed point, 0 when sequential */
     int32_t af_q;            /* fixed-point scale: scores = sum / 2^q */
     int32_t n_chunks;
+    int64_t decr_iterations;   /* iterations scored decrementally (0 unless enabled) */
+    int64_t brute_force_bytes; /* what full re-scoring of every iteration would have had to read */
 } utm_stats;
 
 const char *utm_last_error(void);
@@ -131,6 +134,12 @@ int utm_peek_scores(utm_ctx *ctx, int64_t *counts, double *scores);
 /* Current covered mask of a chunk (all pending updates applied), ceil(n_var/64) words. */
 int utm_get_covered(utm_ctx *ctx, int32_t chunk, uint64_t *out);
 int utm_get_stats(utm_ctx *ctx, utm_stats *out);
+/* Decremental scoring: after a full scoring pass, later iterations only subtract the
+ * contribution of the variants the last winner newly covered (counts and fixed-point AF sums stay exact;
+ * same rows).  Reads far fewer bytes than the brute-force loop, so it is off by default and its numbers
+ * are reported separately from the brute-force roofline.  threshold = largest fraction of a column's
+ * words that may be newly covered for an iteration to go decremental (<= 0: default 0.05). */
+int utm_set_decremental(utm_ctx *ctx, int32_t on, double threshold);
 /* Switch per-launch HIP-event timing of the scoring kernels on/off (same as UTM_FLAG_PROFILE_EVENTS). */
 int utm_set_profile(utm_ctx *ctx, int32_t on);
 

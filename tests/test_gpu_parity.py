@@ -24,7 +24,7 @@ def make_matrix(dev, cols, n_var, **kw):
     return m
 
 
-def check_run(dev, dense, state=None, weights=None, af=None, k=None, chunks=None, **kw):
+def check_run(dev, dense, state=None, weights=None, af=None, k=None, chunks=None, decremental=None, **kw):
     n_var, n_samp = dense.shape
     state = np.ones(n_samp, np.uint8) if state is None else state
     cols = npo.pack_columns(dense)
@@ -39,6 +39,8 @@ def check_run(dev, dense, state=None, weights=None, af=None, k=None, chunks=None
                 m.set_af(c, af[lo:hi])
         m.set_state(state)
         m.set_weights(weights)
+        if decremental is not None:
+            m.set_decremental(True, decremental)
         got = m.run(n_samp if k is None else k)
         stats = m.stats()
     finally:
@@ -358,3 +360,43 @@ def test_two_processes_share_the_gpu_host_staged_exchange(dev):
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] for r in res) and res[0][2] == res[1][2] > 50
+
+
+@pytest.mark.parametrize("mode", ["int", "weights", "af32", "af64", "chunks"])
+def test_decremental_scoring_gives_the_same_rows(dev, mode):
+    """later iterations only subtract what the last winner newly covered; same rows, and the
+    device really ran decremental iterations."""
+    rng = np.random.default_rng(30)
+    n_var, n_samp = 64 * 128 * 6 + 99, 150
+    dense = ou.random_dense(rng, n_var, n_samp)
+    kw = {}
+    if mode == "weights":
+        kw["weights"] = rng.choice([0.5, 1.0, 2.0, -1.0], n_samp)
+    if mode == "af32":
+        kw["af"] = (dense.sum(axis=1) / (2.0 * n_samp)).astype(np.float32)
+    if mode == "af64":
+        kw["af"] = dense.sum(axis=1) / (2.0 * n_samp) / 3.0
+    if mode == "chunks":
+        kw["chunks"] = [0, 8192, 20000, n_var]
+    state = np.ones(n_samp, np.uint8)
+    state[[1, 50]] = 2
+    _, stats = check_run(dev, dense, state=state, decremental=1.0, **kw)   # threshold 1.0: decremental from the 2nd batch on
+    assert stats["decr_iterations"] > 0
+    assert stats["algo_bytes"] < stats["brute_force_bytes"]
+
+
+def test_decremental_survives_peek_and_covered_reads(dev):
+    rng = np.random.default_rng(31)
+    n_var, n_samp = 30000, 90
+    dense = ou.random_dense(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8))
+    with make_matrix(dev, cols, n_var) as m:
+        m.set_decremental(True, 1.0)
+        got_idx = []
+        for chunk in (70, 3, 17):
+            idx, _, _ = m.run(chunk)
+            got_idx += idx.tolist()
+            m.peek_scores()            # applies the pending winner outside the loop: next pass must be a full one
+            m.covered(0)
+        assert got_idx == exp[0][:len(got_idx)].tolist()

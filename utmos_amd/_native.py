@@ -9,6 +9,7 @@ UTM_OK = 0
 AF_NONE, AF_F32, AF_F64 = 0, 1, 2
 FLAG_PROFILE_EVENTS = 1
 FLAG_AF_SEQUENTIAL = 2
+FLAG_DECREMENTAL = 4
 UNIQUE_ID_BYTES = 128
 
 
@@ -30,7 +31,8 @@ class Stats(ctypes.Structure):
                 ("score_launches", ctypes.c_int64), ("score_ms", ctypes.c_double),
                 ("loop_ms", ctypes.c_double), ("algo_bytes", ctypes.c_int64),
                 ("af_mode", ctypes.c_int32), ("af_fixed_point", ctypes.c_int32),
-                ("af_q", ctypes.c_int32), ("n_chunks", ctypes.c_int32)]
+                ("af_q", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
+                ("decr_iterations", ctypes.c_int64), ("brute_force_bytes", ctypes.c_int64)]
 
 
 _P = ctypes.c_void_p
@@ -59,6 +61,7 @@ PROTOTYPES = {
     "utm_get_covered": [_P, _I32, _P],
     "utm_get_stats": [_P, ctypes.POINTER(Stats)],
     "utm_set_profile": [_P, _I32],
+    "utm_set_decremental": [_P, _I32, ctypes.c_double],
     "utm_local_best": [_P, ctypes.POINTER(Record)],
     "utm_column_words": [_P, ctypes.POINTER(_U64)],
     "utm_get_column": [_P, _I64, _P],

@@ -33,6 +33,9 @@ struct IterState {
     int need_chain;     // some candidate's parallel sum is not provably the reference's float64 sum
     int cand_overflow;  // more candidates than UTM_MAX_CAND: every sample is re-scored sequentially
     int all_exact;      // every selectable sample's estimate is exact; scores only shrink, so it stays that way
+    // decremental scoring: work actually done (for the byte accounting)
+    u64 decr_entries;   // sum over decremental iterations of the newly-covered word count
+    u64 decr_gathers;   // ... of (selectable samples x newly-covered words)
 };
 
 #define UTM_MAX_CAND 64
@@ -70,8 +73,13 @@ struct PickArgs {
     unsigned *act;
     unsigned char *state;
     const double *weights;  // n_samp_total, or nullptr
-    u64 *cnt;
+    u64 *cnt;        // per-sample counts to read (accumulators, or the persistent copy in decremental mode)
     i64 *afsum;      // fixed-point AF sums, or nullptr
+    u64 *cnt_mirror; // full mode: copy every count here (the persistent copy decremental iterations update), else nullptr
+    i64 *afsum_mirror;
+    int zero_after;  // full mode: clear the accumulators for the next iteration's atomics
+    unsigned *list_n;  // decremental mode: per-chunk newly-covered word counts (read for the accounting, then cleared)
+    int n_chunks;
     double *fscore;  // sequential AF scores, or nullptr
     double af_scale; // 2^-q
     CandBuf *cand;   // verified-parallel AF: candidate list, else nullptr
@@ -462,6 +470,73 @@ __global__ __launch_bounds__(256) void k_or_column(u64 *__restrict__ covered, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Decremental scoring (optional, reported separately from the brute-force roofline).
+// Coverage only grows, so count_{k+1}[s] = count_k[s] - popcount(col_s & newly_k) with
+// newly_k = winner_k & ~covered_k, and only the words where newly_k != 0 have to be touched.
+// k_newly applies the pending winner to `covered` and compacts those words into a list; k_decr lets
+// one wave per selectable sample gather its own words at the listed positions and subtract.  Integer
+// arithmetic on both sides: the counts (and the fixed-point AF sums) stay exactly what a full
+// re-scoring would give.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_newly(u64 *__restrict__ covered, const u64 *__restrict__ cols, u64 wp,
+                                               const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                               const IterState *__restrict__ st, unsigned *__restrict__ list_idx,
+                                               u64 *__restrict__ list_val, unsigned *__restrict__ list_n)
+{
+    if (st->done) return;
+    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    if (!wcol) return;
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) {
+        const u64 c = covered[w];
+        const u64 x = wcol[w] & ~c;
+        if (x) {
+            const unsigned slot = atomicAdd(list_n, 1u);
+            list_idx[slot] = (unsigned)w;
+            list_val[slot] = x;
+            covered[w] = c | x;
+        }
+    }
+}
+
+template <bool AF>
+__global__ __launch_bounds__(256) void k_decr(const u64 *__restrict__ cols, u64 wp, const unsigned *__restrict__ afbits,
+                                              int e_base, const IterState *__restrict__ st,
+                                              const unsigned *__restrict__ act, const unsigned *__restrict__ list_idx,
+                                              const u64 *__restrict__ list_val, const unsigned *__restrict__ list_n,
+                                              u64 *__restrict__ cnt, i64 *__restrict__ afsum)
+{
+    if (st->done) return;
+    const unsigned n = *list_n;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned i = blockIdx.x * 4 + wave;
+    if (i >= st->n_active || blockIdx.y * 64 >= n) return;
+    const unsigned s = act[i];
+    const u64 *col = cols + (u64)s * wp;
+    unsigned dec = 0;
+    u64 dsum = 0;
+    for (unsigned e = blockIdx.y * 64 + lane; e < n; e += gridDim.y * 64) {
+        const unsigned w = list_idx[e];
+        u64 x = col[w] & list_val[e];
+        dec += __popcll(x);
+        if (AF) {
+            const unsigned *a = afbits + (u64)w * 64;
+            while (x) {
+                dsum += af_fixed(a[__builtin_ctzll(x)], e_base);
+                x &= x - 1;
+            }
+        }
+    }
+    const unsigned total = wave_sum_u32(dec);
+    if (total) {  // wave uniform
+        const i64 tsum = AF ? wave_sum_u63(dsum) : 0;
+        if (lane == 0) {
+            atomicAdd(&cnt[s], (u64)0 - (u64)total);
+            if (AF) atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), (u64)0 - (u64)tsum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Verified-parallel AF scoring.  The reference's AF score of a sample is a float64 running sum in
 // ascending variant order (select.py:40); float64 addition does not reassociate, so a parallel sum is
 // only an *estimate* E with a rigorous bound B on |reference - E|:
@@ -699,11 +774,13 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
     for (unsigned i = threadIdx.x; i < n_active; i += 1024) {
         const unsigned s = a.act[i];
         const u64 c = a.cnt[s];
-        a.cnt[s] = 0;  // ready for the next iteration's atomics
+        if (a.zero_after) a.cnt[s] = 0;  // ready for the next iteration's atomics
+        if (a.cnt_mirror) a.cnt_mirror[s] = c;
         double v = (double)c;
         if (a.afsum) {
             const i64 q = a.afsum[s];
-            a.afsum[s] = 0;
+            if (a.zero_after) a.afsum[s] = 0;
+            if (a.afsum_mirror) a.afsum_mirror[s] = q;
             v = (double)q * a.af_scale;  // exact: q < 2^53 whenever this value is used, and the scale is a power of two
         }
         if (src == 3) continue;
@@ -727,6 +804,15 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
         rc->idx = n_active ? best.gidx : -1;
         rc->new_count = n_active ? best.cnt : 0;
         st->best_pos = best.pos;
+        if (a.list_n) {
+            u64 n_l = 0;
+            for (int c = 0; c < a.n_chunks; ++c) {
+                n_l += a.list_n[c];
+                a.list_n[c] = 0;
+            }
+            st->decr_entries += n_l;
+            st->decr_gathers += n_l * n_active;
+        }
         if (DECIDE) decide(a);
     }
 }

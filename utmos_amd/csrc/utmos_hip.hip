@@ -99,6 +99,8 @@ struct Chunk {
     u64 *covered = nullptr;
     void *af = nullptr;    // device: AF in its own type (float or double), wp*64 entries: chains read this
     float *af32 = nullptr; // device: float32 AF for the parallel estimate (== af when the AF is float32)
+    unsigned *list_idx = nullptr;  // decremental scoring: words newly covered by the last winner
+    u64 *list_val = nullptr;
     std::vector<float> h_af32;
     std::vector<double> h_af64;
 };
@@ -128,6 +130,17 @@ struct utm_ctx {
     u64 xbuf_slot_words = UTM_HDR_WORDS;  // slot size the buffer was allocated for
     SeqChunk *d_seq = nullptr;
     CandBuf *d_cand = nullptr;
+    u64 *d_cnt_keep = nullptr;   // persistent per-sample counts (mirror of the last full scoring, then decremented)
+    i64 *d_afsum_keep = nullptr;
+    unsigned *d_listn = nullptr; // per chunk
+    size_t listn_cap = 0;
+    bool decr_enabled = false;
+    double decr_threshold = 0.05;
+    bool keep_valid = false;     // the persistent counts describe the state right before the pending winner
+    i64 last_new = -1;           // new_count of the last row (host copy)
+    i64 decr_iterations = 0;
+    i64 brute_bytes = 0;
+    u64 decr_entries_seen = 0, decr_gathers_seen = 0;
     u64 *d_varcount = nullptr;
     bool varcount_valid = false;
 
@@ -195,6 +208,9 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     HIP_TRY(hipMalloc(&c->d_res_score, ((size_t)n_samp_total + 1) * 8));
     HIP_TRY(hipMalloc(&c->d_xbuf, UTM_HDR_WORDS * 8));
     HIP_TRY(hipMalloc(&c->d_cand, sizeof(CandBuf)));
+    HIP_TRY(hipMalloc(&c->d_cnt_keep, (size_t)n_samp_local * 8));
+    HIP_TRY(hipMalloc(&c->d_afsum_keep, (size_t)n_samp_local * 8));
+    c->decr_enabled = flags & UTM_FLAG_DECREMENTAL;
     c->xbuf_ranks = 1;
     HIP_TRY(hipEventCreate(&c->ev_loop0));
     HIP_TRY(hipEventCreate(&c->ev_loop1));
@@ -212,8 +228,11 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
         (void)hipFree(ch.covered);
         if ((void *)ch.af32 != ch.af) (void)hipFree(ch.af32);
         (void)hipFree(ch.af);
+        (void)hipFree(ch.list_idx);
+        (void)hipFree(ch.list_val);
     }
     (void)hipFree(c->d_cand);
+    (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
     (void)hipFree(c->d_xbuf); (void)hipFree(c->d_seq); (void)hipFree(c->d_varcount);
@@ -588,6 +607,26 @@ extern "C" int utm_reset(utm_ctx *c)
     st.prev_local = -1;
     HIP_TRY(hipMemcpyAsync(c->d_st, &st, sizeof st, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->decr_enabled) {
+        if (c->listn_cap < c->chunks.size()) {
+            (void)hipFree(c->d_listn);
+            c->d_listn = nullptr;
+            HIP_TRY(hipMalloc(&c->d_listn, c->chunks.size() * 4));
+            c->listn_cap = c->chunks.size();
+        }
+        for (auto &ch : c->chunks)
+            if (!ch.list_idx) {
+                HIP_TRY(hipMalloc(&ch.list_idx, ch.wp * 4));
+                HIP_TRY(hipMalloc(&ch.list_val, ch.wp * 8));
+            }
+        HIP_TRY(hipMemsetAsync(c->d_listn, 0, c->chunks.size() * 4, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->keep_valid = false;
+    c->last_new = -1;
+    c->decr_iterations = 0;
+    c->brute_bytes = 0;
+    c->decr_entries_seen = c->decr_gathers_seen = 0;
     c->iter = 0;
     c->captured_seen = 0;
     c->af_all_exact = false;
@@ -608,15 +647,22 @@ static int ensure_prepared(utm_ctx *c)
     return utm_reset(c);
 }
 
-static PickArgs pick_args(utm_ctx *c)
+static PickArgs pick_args(utm_ctx *c, bool decr = false)
 {
     PickArgs a;
     a.st = c->d_st;
     a.act = c->d_act;
     a.state = c->d_state;
     a.weights = c->have_weights ? c->d_weights : nullptr;
-    a.cnt = c->d_cnt;
-    a.afsum = (c->af_mode != UTM_AF_NONE && c->af_fixed) ? c->d_afsum : nullptr;
+    const bool afs = c->af_mode != UTM_AF_NONE && c->af_fixed;
+    a.cnt = decr ? c->d_cnt_keep : c->d_cnt;
+    a.afsum = afs ? (decr ? c->d_afsum_keep : c->d_afsum) : nullptr;
+    // full iterations leave a copy of every count behind: the state decremental iterations continue from
+    a.cnt_mirror = (!decr && c->decr_enabled) ? c->d_cnt_keep : nullptr;
+    a.afsum_mirror = (!decr && c->decr_enabled && afs) ? c->d_afsum_keep : nullptr;
+    a.zero_after = decr ? 0 : 1;
+    a.list_n = decr ? c->d_listn : nullptr;  // read for the accounting, then cleared, by k_pick
+    a.n_chunks = (int)c->chunks.size();
     a.fscore = c->af_mode != UTM_AF_NONE ? c->d_fscore : nullptr;  // sequential scores (fallback / overflow)
     a.af_scale = ldexp(1.0, -c->af_q);
     // float32 AF sums only shrink: once every estimate was exact (< 2^53 units) the plain exact pick suffices
@@ -750,6 +796,29 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
     return UTM_OK;
 }
 
+// Decremental scoring of one iteration: list the words the pending winner newly covers, subtract.
+static int enqueue_score_decr(utm_ctx *c)
+{
+    const unsigned a_ub = std::max(1u, c->active_ub);
+    const bool af = c->af_mode != UTM_AF_NONE;  // (k_pick clears the list counters after reading them)
+    unsigned split = (2048 + a_ub - 1) / a_ub;
+    split = std::min(16u, std::max(1u, split));
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        Chunk &ch = c->chunks[k];
+        hipLaunchKernelGGL(k_newly, dim3((unsigned)std::min<u64>(2048, (ch.wp + 255) / 256)), dim3(256), 0, c->stream, ch.covered,
+                           ch.cols, ch.wp, c->d_xbuf, c->xbuf_slot_words, ch.off, c->d_st, ch.list_idx, ch.list_val, c->d_listn + k);
+        const dim3 grid((a_ub + 3) / 4, split);
+        if (af)
+            hipLaunchKernelGGL(k_decr<true>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, reinterpret_cast<const unsigned *>(ch.af32),
+                               150 - c->af_q, c->d_st, c->d_act, ch.list_idx, ch.list_val, c->d_listn + k, c->d_cnt_keep, c->d_afsum_keep);
+        else
+            hipLaunchKernelGGL(k_decr<false>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, (const unsigned *)nullptr, 0, c->d_st,
+                               c->d_act, ch.list_idx, ch.list_val, c->d_listn + k, c->d_cnt_keep, c->d_afsum_keep);
+    }
+    HIP_TRY(hipGetLastError());
+    return UTM_OK;
+}
+
 // Algorithmic HBM bytes of one iteration with `a` selectable local samples:
 // active columns + covered read + winner column re-read + covered write (+ AF values).
 static i64 iteration_bytes(const utm_ctx *c, u64 a)
@@ -780,9 +849,9 @@ static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
     }
 }
 
-static int enqueue_pick_and_exchange(utm_ctx *c)
+static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
 {
-    PickArgs a = pick_args(c);
+    PickArgs a = pick_args(c, decr);
     enqueue_candidates(c, a);
     if (!c->comm) {
         hipLaunchKernelGGL(k_pick<true>, dim3(1), dim3(1024), 0, c->stream, a);
@@ -843,9 +912,14 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, 8) : batch;
         const i64 n = std::min<i64>(this_batch, k_max - enq);
         const unsigned a0 = c->active_ub;
+        // Decremental batches: only when allowed, when the persistent counts are current, and when the last
+        // winner newly covered few enough variants (gains shrink over a greedy run, so it stays that way).
+        const bool decr = c->decr_enabled && c->keep_valid && c->last_new >= 0 && (c->af_mode == UTM_AF_NONE || c->af_fixed) &&
+                          (double)c->last_new <= c->decr_threshold * (double)c->col_words;
         for (i64 j = 0; j < n; ++j) {
-            TRY(enqueue_score(c));
-            TRY(enqueue_pick_and_exchange(c));
+            if (decr) TRY(enqueue_score_decr(c));
+            else TRY(enqueue_score(c));
+            TRY(enqueue_pick_and_exchange(c, decr));
             if (c->n_ranks == 1 && c->active_ub > 0) c->active_ub -= 1;  // exact while the loop is alive
         }
         enq += n;
@@ -858,8 +932,22 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         const unsigned a1 = c->active_ub;
         for (i64 j = 0; j < passes; ++j) {
             const u64 drop = rows > 0 ? (u64)(a0 - a1) * (u64)std::min(j, rows) / (u64)rows : 0;
-            c->algo_bytes += iteration_bytes(c, a0 - drop);
+            const i64 full = iteration_bytes(c, a0 - drop);
+            c->brute_bytes += full;
+            if (!decr) c->algo_bytes += full;
         }
+        if (decr) {
+            // what the decremental iterations had to touch: winner column + covered (read), the list (written
+            // once, read once), covered words rewritten, and one word per (selectable sample, listed word)
+            const u64 entries = c->h_st->decr_entries - c->decr_entries_seen;
+            const u64 gathers = c->h_st->decr_gathers - c->decr_gathers_seen;
+            c->algo_bytes += (i64)(passes * 2 * (i64)c->col_words * 8 + entries * 32 + gathers * 8);
+            c->decr_iterations += passes;
+        }
+        c->decr_entries_seen = c->h_st->decr_entries;
+        c->decr_gathers_seen = c->h_st->decr_gathers;
+        c->keep_valid = c->decr_enabled;  // a full pass mirrored the counts; a decremental one kept them current
+        if (rows > 0) HIP_TRY(hipMemcpy(&c->last_new, c->d_res_new + c->iter - 1, 8, hipMemcpyDeviceToHost));
         c->scored += passes;
         if (c->flags & UTM_FLAG_PROFILE_EVENTS) TRY(collect_event_times(c));
     }
@@ -897,6 +985,7 @@ extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
     CTX(c);
     TRY(ensure_prepared(c));
     // with AF every sample's exact reference score is wanted, so all of them take the sequential chain
+    c->keep_valid = false;  // the pending winner gets applied here: the next iteration must re-score in full
     TRY(enqueue_score(c, /*force_sequential=*/true));
     i64 *d_counts = nullptr;
     double *d_scores = nullptr;
@@ -933,6 +1022,7 @@ extern "C" int utm_get_covered(utm_ctx *c, int32_t chunk, uint64_t *out)
     TRY(chunk_of(c, chunk, &ch));
     if (!out) return fail(UTM_EINVAL, "out is NULL");
     TRY(ensure_prepared(c));
+    c->keep_valid = false;
     TRY(flush_pending(c));
     HIP_TRY(hipMemcpyAsync(out, ch->covered, ch->w * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -954,6 +1044,17 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->af_fixed_point = c->af_fixed;
     out->af_q = c->af_q;
     out->n_chunks = (int32_t)c->chunks.size();
+    out->decr_iterations = c->decr_iterations;
+    out->brute_force_bytes = c->brute_bytes;
+    return UTM_OK;
+}
+
+extern "C" int utm_set_decremental(utm_ctx *c, int32_t on, double threshold)
+{
+    CTX(c);
+    c->decr_enabled = on != 0;
+    c->decr_threshold = threshold > 0 ? threshold : 0.05;
+    c->prepared = false;  // buffers are allocated at the next reset
     return UTM_OK;
 }
 
@@ -982,6 +1083,7 @@ extern "C" int utm_local_best(utm_ctx *c, utm_record *rec)
     memset(rec, 0, sizeof *rec);
     rec->idx = -1;
     if (c->finished) return UTM_OK;
+    c->keep_valid = false;
     TRY(enqueue_score(c));
     PickArgs a = pick_args(c);
     enqueue_candidates(c, a);

@@ -154,6 +154,10 @@ class DeviceMatrix:
         nat.check(nat.lib().utm_get_stats(self._h, ctypes.byref(st)))
         return {name: getattr(st, name) for name, _ in nat.Stats._fields_}
 
+    def set_decremental(self, on, threshold=0.0):
+        """Allow decremental scoring for later iterations (exact; fewer bytes; reported separately)."""
+        nat.check(nat.lib().utm_set_decremental(self._h, 1 if on else 0, float(threshold)))
+
     def set_profile(self, on):
         nat.check(nat.lib().utm_set_profile(self._h, 1 if on else 0))
 
