@@ -225,17 +225,15 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0):
 # Input utilities #
 ###################
 def parse_sample_lists(argument):
-    """--exclude/--subset: file names and/or comma separated lists."""
-    ret = []
-    if not argument:
-        return ret
-    for i in argument:
-        if os.path.exists(i):
-            with open(i, "r") as fh:
-                ret.extend([_.strip() for _ in fh])
+    """--subset / --exclude values: each item is a file of names (one per line) or a comma separated list."""
+    names = []
+    for item in argument or []:
+        if os.path.exists(item):
+            with open(item, "r") as fh:
+                names += [line.strip() for line in fh]
         else:
-            ret.extend(i.split(","))
-    return ret
+            names += item.split(",")
+    return names
 
 
 def parse_weights(argument):
@@ -257,53 +255,55 @@ def setup_logging(debug=False):
                         format="%(asctime)s [%(levelname)s] %(message)s", force=True)
 
 
+# (flags, keyword arguments) -- the option surface of the reference's `utmos select` (utmos/select.py:355-398)
+_GENERAL = [
+    (("in_files",), dict(nargs="*", type=str, help="inputs: .vcf[.gz], .jl, .npz parts, or one packed .utm store")),
+    (("-c", "--count"), dict(type=float, default=0.02,
+                            help="how many samples: a fraction of all if < 1, a count if >= 1, every sample if -1 [%(default)s]")),
+    (("-o", "--out"), dict(type=str, default="/dev/stdout", help="TSV destination [stdout]")),
+    (("--debug",), dict(action="store_true", help="debug-level logging")),
+]
+_SCORING = [
+    (("--af",), dict(action="store_true", help="score variants by allele frequency instead of 1")),
+    (("--weights",), dict(type=str, default=None, help="two-column TSV: sample, weight")),
+    (("--subset",), dict(type=str, default=None, action="append", help="only consider these samples (file or comma list; repeatable)")),
+    (("--exclude",), dict(type=str, default=None, action="append", help="never select these samples (file or comma list; repeatable)")),
+]
+_MEMORY = [
+    (("--lowmem",), dict(type=str, default=None, help="packed matrix store (.utm) to write, or to read when no inputs are given")),
+    (("--buffer",), dict(type=int, default=32768, help="variants per HBM chunk when chunking is on [%(default)s]")),
+    (("--maxmem",), dict(type=int, default=2, help="GB one chunk may take; 0 = always chunk [%(default)s]")),
+    (("--device",), dict(type=int, default=0, help="GPU index [%(default)s]")),
+]
+
+
 def parse_args(args):
-    """Same flags as the reference (utmos/select.py:355-418); `.utm` takes the place of `.hdf5`."""
-    parser = argparse.ArgumentParser(prog="select", description=__doc__,
-                                     formatter_class=argparse.RawDescriptionHelpFormatter)
-    parser.add_argument("in_files", nargs="*", type=str, help="Input VCF, jl or npz files")
-    parser.add_argument("-c", "--count", type=float, default=0.02,
-                        help="Number of samples to select as a percent if <1 or count if >=1 or -1 for all (%(default)s)")
-    parser.add_argument("-o", "--out", type=str, default="/dev/stdout", help="Output file (stdout)")
-    parser.add_argument("--debug", action="store_true", help="Verbose logging")
-
-    scoreg = parser.add_argument_group("Scoring Arguments")
-    scoreg.add_argument("--af", action="store_true", help="Weigh variants by allele frequency")
-    scoreg.add_argument("--weights", type=str, default=None, help="Tab-delimited file of sample weights")
-    scoreg.add_argument("--subset", type=str, default=None, action="append",
-                        help="Filename with or Comma-separated list of samples to analyze")
-    scoreg.add_argument("--exclude", type=str, default=None, action="append",
-                        help="Filename with or Comma-separated list of samples to exclude selection")
-
-    mperfg = parser.add_argument_group("Memory Arguments")
-    mperfg.add_argument("--lowmem", type=str, default=None,
-                        help="Name of packed matrix store (.utm) to create/use (%(default)s)")
-    mperfg.add_argument("--buffer", type=int, default=32768,
-                        help="Number of variants per chunk when chunking (%(default)s)")
-    mperfg.add_argument("--maxmem", type=int, default=2,
-                        help="Maximum HBM (GB) of one chunk. 0 forces chunking (%(default)s)")
-    mperfg.add_argument("--device", type=int, default=0, help="GPU to use (%(default)s)")
-
+    """Parse and validate the command line; exits with status 1 on unusable input combinations."""
+    parser = argparse.ArgumentParser(prog="select", description="Select the fewest samples that capture the most variants (MI355X).")
+    for flags, kw in _GENERAL:
+        parser.add_argument(*flags, **kw)
+    for title, table in (("Scoring Arguments", _SCORING), ("Memory Arguments", _MEMORY)):
+        group = parser.add_argument_group(title)
+        for flags, kw in table:
+            group.add_argument(*flags, **kw)
     args = parser.parse_args(args)
     setup_logging(args.debug)
-    if [_ for _ in args.in_files if _.endswith((STORE_SUFFIX, ".hdf5"))] and len(args.in_files) > 1:
-        logging.error("Cannot provide a matrix store with multiple input files")
+
+    stores = [f for f in args.in_files if f.endswith((STORE_SUFFIX, ".hdf5"))]
+    if stores and len(args.in_files) > 1:
+        logging.error("A matrix store cannot be combined with other input files")
         sys.exit(1)
-    if [_ for _ in args.in_files if _.endswith(".hdf5")] or (args.lowmem or "").endswith(".hdf5"):
+    if any(f.endswith(".hdf5") for f in args.in_files) or (args.lowmem or "").endswith(".hdf5"):
         logging.error("hdf5 stores are not read by this build; recreate with --lowmem FILE%s", STORE_SUFFIX)
         sys.exit(1)
-
-    if len(args.in_files) == 0:
+    if not args.in_files:
         if not args.lowmem:
             logging.error("No input files provided")
             sys.exit(1)
-        args.in_files = [args.lowmem]
+        args.in_files, args.lowmem = [args.lowmem], 1      # reuse an existing store
+    elif stores and not args.lowmem:
+        logging.info("Input is a matrix store: reading it directly")
         args.lowmem = 1
-
-    if len(args.in_files) == 1 and args.in_files[0].endswith(STORE_SUFFIX) and not args.lowmem:
-        logging.info("Switching on lowmem for store input")
-        args.lowmem = 1
-
     logging.info("Params:\n%s", json.dumps(vars(args), indent=4))
     return args
 
