@@ -629,55 +629,75 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
 // candidate's surviving bits, in ascending variant order, into LDS (popcount -> block prefix sum ->
 // scatter); lane 0 then adds them one by one in float64.  Only the additions are serial.
 #define UTM_CHAIN_CAP 2048
+#define UTM_CHAIN_WPT 4  // consecutive words per lane and round: 4096 words (262,144 variants) per round
 template <typename AF_T>
 __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chunks, int n_chunks,
                                                 const IterState *__restrict__ st, CandBuf *__restrict__ cand)
 {
     __shared__ double buf[UTM_CHAIN_CAP];
-    __shared__ unsigned wtot[16];
+    __shared__ unsigned wtot[2][16];  // double buffered: one barrier per empty round
     if (st->done || !st->need_chain || st->cand_overflow || (int)blockIdx.x >= st->n_cand) return;
     const unsigned s = cand->samp[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc = 0.0;
+    unsigned round = 0;
     for (int c = 0; c < n_chunks; ++c) {
         const SeqChunk ch = chunks[c];
         const u64 *col = ch.cols + (u64)s * ch.wp;
         const AF_T *af = static_cast<const AF_T *>(ch.af);
-        u64 x_next = (u64)tid < ch.w ? (col[tid] & ~ch.covered[tid]) : 0;
-        for (u64 w0 = 0; w0 < ch.w; w0 += 1024) {
-            const u64 w = w0 + tid;
-            const u64 x = x_next;
-            const u64 wn = w + 1024;
-            x_next = wn < ch.w ? (col[wn] & ~ch.covered[wn]) : 0;  // in flight during this round
-            const unsigned n = __popcll(x);
+        // wp is a multiple of 128 words, so whole groups of UTM_CHAIN_WPT words never straddle its end
+        auto fetch = [&](u64 w, u64 *x) {
+#pragma unroll
+            for (int k = 0; k < UTM_CHAIN_WPT; ++k) x[k] = w + k < ch.w ? (col[w + k] & ~ch.covered[w + k]) : 0;
+        };
+        u64 x_next[UTM_CHAIN_WPT];
+        fetch((u64)tid * UTM_CHAIN_WPT, x_next);
+        for (u64 w0 = 0; w0 < ch.w; w0 += 1024 * UTM_CHAIN_WPT, ++round) {
+            const u64 w = w0 + (u64)tid * UTM_CHAIN_WPT;
+            u64 x[UTM_CHAIN_WPT];
+            unsigned n = 0;
+#pragma unroll
+            for (int k = 0; k < UTM_CHAIN_WPT; ++k) {
+                x[k] = x_next[k];
+                n += __popcll(x[k]);
+            }
+            fetch(w + 1024 * UTM_CHAIN_WPT, x_next);  // in flight during this round
             const unsigned incl = wave_scan_incl_u32(n);
-            if (lane == 63) wtot[wave] = incl;
+            unsigned *wt = wtot[round & 1];
+            if (lane == 63) wt[wave] = incl;
             __syncthreads();
             unsigned woff = 0, total = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const unsigned t = wtot[k];
+                const unsigned t = wt[k];
                 woff += k < wave ? t : 0;
                 total += t;
             }
-            if (total == 0) {
-                __syncthreads();
-                continue;
-            }
+            if (total == 0) continue;  // the other wtot buffer is written next round
             const unsigned off = woff + incl - n;
             for (unsigned base = 0; base < total; base += UTM_CHAIN_CAP) {
-                u64 y = x;
                 unsigned p = off;
-                while (y) {
-                    const int b = __builtin_ctzll(y);
-                    y &= y - 1;
-                    if (p >= base && p < base + UTM_CHAIN_CAP) buf[p - base] = (double)af[w * 64 + b];
-                    ++p;
+#pragma unroll
+                for (int k = 0; k < UTM_CHAIN_WPT; ++k) {
+                    u64 y = x[k];
+                    while (y) {
+                        const int b = __builtin_ctzll(y);
+                        y &= y - 1;
+                        if (p >= base && p < base + UTM_CHAIN_CAP) buf[p - base] = (double)af[(w + k) * 64 + b];
+                        ++p;
+                    }
                 }
                 __syncthreads();
                 if (tid == 0) {
                     const unsigned m = total - base < UTM_CHAIN_CAP ? total - base : UTM_CHAIN_CAP;
-                    for (unsigned t = 0; t < m; ++t) acc += buf[t];
+                    unsigned t = 0;
+                    for (; t + 8 <= m; t += 8) {  // loads up front, then the strictly ordered additions
+                        const double v0 = buf[t], v1 = buf[t + 1], v2 = buf[t + 2], v3 = buf[t + 3];
+                        const double v4 = buf[t + 4], v5 = buf[t + 5], v6 = buf[t + 6], v7 = buf[t + 7];
+                        acc += v0; acc += v1; acc += v2; acc += v3;
+                        acc += v4; acc += v5; acc += v6; acc += v7;
+                    }
+                    for (; t < m; ++t) acc += buf[t];
                 }
                 __syncthreads();
             }
