@@ -49,28 +49,8 @@ def parse():
 
 
 def rendezvous_id(rank, world, make_id):
-    """Rank 0 publishes the 128-byte ncclUniqueId in a file every rank of this launch can name."""
-    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"utmos_amd_ncclid_{key}")
-    if rank == 0:
-        uid = make_id()
-        tmp = path + f".{os.getpid()}"
-        with open(tmp, "wb") as fh:
-            fh.write(uid)
-        os.replace(tmp, path)
-        return uid, path
-    deadline = time.time() + 300
-    while time.time() < deadline:
-        try:
-            if os.path.getmtime(path) >= T_START - 600:      # never a leftover of an older launch
-                with open(path, "rb") as fh:
-                    uid = fh.read()
-                if len(uid) == 128:
-                    return uid, path
-        except FileNotFoundError:
-            pass
-        time.sleep(0.05)
-    raise RuntimeError(f"rank {rank}: no ncclUniqueId at {path} after 300 s")
+    from utmos_amd.sharded import rendezvous_unique_id
+    return rendezvous_unique_id(rank, make_id)
 
 
 def cpu_baseline(args, device_mod):

@@ -103,3 +103,35 @@ def test_calculate_scores_drop_in(tmp_path):
         assert (use, new) == (e_use, e_new)
         mask[:] = 0
         assert calculate_scores(m, mask) == (None, None)
+
+
+def _cli_rank(rank, world, port, argv, q):
+    import os
+    os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "UTMOS_TRANSPORT": "socket"})
+    try:
+        from utmos_amd.select import select_main
+        select_main(argv + ["--device", "0"])
+        q.put((rank, "ok"))
+    except BaseException as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+@pytest.mark.parametrize("name", ["select_multi", "select_af", "select_weights_subset"])
+def test_cli_two_processes_sharded_over_samples(name, tmp_path):
+    """`utmos select` as one process per shard (here both on the box's single GPU, host-staged exchange):
+    rank 0 writes the golden TSV."""
+    import multiprocessing as mp
+    import os
+    argv, out = cli_args(CASES[name], tmp_path)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_cli_rank, args=(r, 2, port, argv, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == {0: "ok", 1: "ok"}
+    assert open(out).read() == ou.golden_text(CASES[name])

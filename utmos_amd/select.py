@@ -61,7 +61,7 @@ def is_memsafe(shape, with_af=False):
 # Algorithms #
 ##############
 def greedy_select(matrix, total_variant_count, select_count, vcf_samples, sample_mask, sample_weights=None,
-                  batch=64):
+                  batch=64, transport=None):
     """Greedy calculation; yields each selected sample's row.
 
     matrix:              device.DeviceMatrix (bit-packed, HBM resident)
@@ -70,6 +70,8 @@ def greedy_select(matrix, total_variant_count, select_count, vcf_samples, sample
     vcf_samples:         sample names, lines up with sample_mask
     sample_mask:         1 = can be selected, 0 = used, 2 = excluded; updated in place like the reference
     sample_weights:      optional per-sample weights
+    transport:           host-staged exchange between shards (sharded.SocketTransport / TorchDistTransport);
+                         None = single GPU, or RCCL already initialised on the matrix (run() is then collective)
     """
     num_vars = matrix.shape[0]
     tot_captured = 0
@@ -77,9 +79,17 @@ def greedy_select(matrix, total_variant_count, select_count, vcf_samples, sample
     matrix.set_weights(sample_weights)
     matrix.reset()
     remaining = int(select_count)
+    staged = None
+    if transport is not None:
+        from .sharded import sharded_greedy
+        staged = sharded_greedy(matrix, transport, remaining)
     while remaining > 0:
         want = min(batch, remaining)
-        idx, new, _ = matrix.run(want)          # device-resident: up to `want` iterations, no host round trips
+        if staged is None:
+            idx, new, _ = matrix.run(want)      # device-resident: up to `want` iterations, no host round trips
+        else:
+            rows = [row for _, row in zip(range(want), staged)]
+            idx, new = [r[0] for r in rows], [np.int64(r[1]) for r in rows]
         for use_sample, new_variant_count in zip(idx, new):
             tot_captured += new_variant_count   # np.int64, as in the reference
             sample_mask[use_sample] = 0
@@ -97,7 +107,7 @@ def greedy_select(matrix, total_variant_count, select_count, vcf_samples, sample
 ####################
 # Setup/Management #
 ####################
-def run_selection(data, select_count=0.02, subset=None, exclude=None, weights=None):
+def run_selection(data, select_count=0.02, subset=None, exclude=None, weights=None, transport=None):
     """Set up the selection: select_count in [0,1) = fraction, >= 1 = count, < 0 = all."""
     num_vars, num_samples = data["data"].shape
     logging.info("Sample Count %d", num_samples)
@@ -129,7 +139,7 @@ def run_selection(data, select_count=0.02, subset=None, exclude=None, weights=No
                 sample_weights[pos] = weights[name]
 
     return greedy_select(data["data"], np.asarray(data["var_count"]), select_count, vcf_samples, sample_mask,
-                         sample_weights)
+                         sample_weights, transport=transport)
 
 
 def _read_part(path):
@@ -160,21 +170,31 @@ def save_store(path, data, af_parts):
         np.savez(fh, **arrays)
 
 
-def load_store(path, dev=0):
+def _shard_matrix(n_samples, dev, shard):
+    """shard = (rank, world) or None: this process holds a contiguous block of the sample axis."""
+    if shard is None or shard[1] == 1:
+        return device.DeviceMatrix(n_samples, device=dev)
+    from .sharded import shard_bounds
+    first, n_local = shard_bounds(n_samples, *shard)
+    return device.DeviceMatrix(n_samples, device=dev, first_sample=first, n_local=n_local)
+
+
+def load_store(path, dev=0, shard=None):
     with np.load(path, allow_pickle=False) as z:
         samples = z["samples"]
-        matrix = device.DeviceMatrix(len(samples), device=dev)
+        matrix = _shard_matrix(len(samples), dev, shard)
+        lo, hi = matrix.first_sample, matrix.first_sample + matrix.n_local
         has_af = bool(z["has_af"])
         for c, n_var in enumerate(z["chunk_vars"]):
             idx = matrix.add_chunk(int(n_var))
-            matrix.upload_columns(idx, z[f"cols{c}"])
+            matrix.upload_columns(idx, z[f"cols{c}"][lo:hi])
             if has_af:
                 matrix.set_af(idx, z[f"af{c}"])
         return {"samples": samples, "data": matrix, "var_count": z["var_count"], "has_af": has_af}
 
 
 # pylint: disable=too-many-locals
-def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0):
+def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0, shard=None):
     """Load and concatenate inputs into one HBM-resident matrix.
 
     lowmem == 1: in_files[0] is an existing packed store.  lowmem == path: the store is (re)created
@@ -184,7 +204,11 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0):
     """
     logging.info("Loading %d files", len(in_files))
     if lowmem == 1:
-        return load_store(in_files[0], dev)
+        return load_store(in_files[0], dev, shard)
+    sharded = shard is not None and shard[1] > 1
+    if sharded and lowmem is not None:
+        logging.error("Create the matrix store with a single process, then select from it with several")
+        sys.exit(1)
 
     samples = None
     matrix = None
@@ -193,12 +217,16 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0):
         dat = _read_part(path)
         if samples is None:
             samples = np.asarray(dat["samples"]).astype("U")
-            matrix = device.DeviceMatrix(len(samples), device=dev)
+            matrix = _shard_matrix(len(samples), dev, shard)
+            host_var_count = np.zeros(len(samples), dtype=np.int64)
         rows = np.ascontiguousarray(dat["GT"], dtype=np.uint8)
         informative = rows.any(axis=1)          # a row without carriers has no set bit in any byte
         logging.debug("fitering %d uninformative variants", int((~informative).sum()))
         rows = rows[informative]
         af = np.asarray(dat["AF"], dtype=np.float64).reshape(-1)[informative]
+        if sharded:     # every shard reports var_count for all samples: counted on the host from the packed rows
+            for lo in range(0, len(rows), 65536):
+                host_var_count += np.unpackbits(rows[lo:lo + 65536], axis=1, count=len(samples)).sum(axis=0, dtype=np.int64)
         # one chunk per `step` variants: everything in one chunk unless the estimate says otherwise
         step = len(rows) if (MAXMEM != 0 and is_memsafe((len(rows), len(samples)), calc_af)) else max(64, buffer // 64 * 64)
         for lo in range(0, len(rows), step):
@@ -209,7 +237,8 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0):
         logging.debug("Loaded %d of %d", load_count + 1, len(in_files))
 
     ret = {"samples": samples, "data": matrix}
-    ret["var_count"] = matrix.var_count()       # before AF == 0 rows are cleared, like select.py:281-284
+    # before AF == 0 rows are cleared, like select.py:281-284
+    ret["var_count"] = host_var_count if sharded else matrix.var_count()
     if calc_af:
         as32 = lowmem is not None
         for chunk, af in enumerate(af_parts):
@@ -318,7 +347,22 @@ def select_main(cmdargs):
             logging.error("Input %s does not exist", path)
             sys.exit(1)
 
-    data = load_files(args.in_files, args.lowmem, args.buffer, args.af, args.device)
+    # one process per GPU (torchrun-style RANK / WORLD_SIZE / LOCAL_RANK): each holds a block of the samples
+    from .sharded import SocketTransport, dist_env, rendezvous_unique_id
+    rank, world, local_rank = dist_env()
+    shard = (rank, world) if world > 1 else None
+    dev = local_rank if world > 1 and "--device" not in cmdargs else args.device
+    data = load_files(args.in_files, args.lowmem, args.buffer, args.af, dev, shard)
+    transport = None
+    if world > 1:
+        if os.environ.get("UTMOS_TRANSPORT", "rccl") == "socket":   # host-staged exchange (tests, hosts without RCCL)
+            transport = SocketTransport(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                        int(os.environ.get("MASTER_PORT", "29617")) + 1)
+        else:
+            uid, _ = rendezvous_unique_id(rank, device.DeviceMatrix.comm_unique_id)
+            data["data"].comm_init(rank, world, uid)
+        if rank != 0:
+            args.out = os.devnull
     if not data["has_af"] and args.af:
         logging.critical("Store doesn't appear to be created with --af weighted scores, remove --af or recreate it")
         sys.exit(1)
@@ -331,9 +375,11 @@ def select_main(cmdargs):
 
     with open(args.out, "w") as fout:
         fout.write(HEADER)
-        for result in run_selection(data, args.count, args.subset, args.exclude, args.weights):
+        for result in run_selection(data, args.count, args.subset, args.exclude, args.weights, transport):
             logging.info("Selected %s (%.1f%% of variants)", result[0], result[4] * 100)
             fout.write("\t".join([str(_) for _ in result]) + "\n")
             fout.flush()
+    if transport is not None:
+        transport.close()
     data["data"].close()
     logging.info("Finished utmos")

@@ -137,6 +137,41 @@ class SocketTransport:
             c.close()
 
 
+def dist_env():
+    """(rank, world, local_rank) of a one-process-per-GPU launch (torchrun-style environment), else (0, 1, 0)."""
+    import os
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
+
+
+def rendezvous_unique_id(rank, make_id, timeout=300.0):
+    """Share rank 0's 128-byte ncclUniqueId through a file every rank of this launch can name
+    (same MASTER_PORT, run id and parent process = the launcher)."""
+    import os
+    import time
+    started = time.time()
+    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"utmos_amd_ncclid_{key}")
+    if rank == 0:
+        uid = make_id()
+        tmp = f"{path}.{os.getpid()}"
+        with open(tmp, "wb") as fh:
+            fh.write(uid)
+        os.replace(tmp, path)
+        return uid, path
+    while time.time() - started < timeout:
+        try:
+            if os.path.getmtime(path) >= started - 600:      # never a leftover of an older launch
+                with open(path, "rb") as fh:
+                    uid = fh.read()
+                if len(uid) == 128:
+                    return uid, path
+        except FileNotFoundError:
+            pass
+        time.sleep(0.05)
+    raise RuntimeError(f"rank {rank}: no ncclUniqueId at {path} after {timeout:.0f} s")
+
+
 def sharded_greedy(shard, transport, select_count):
     """Yield (global idx, new_count, score) per selected sample; identical on every rank.
 
