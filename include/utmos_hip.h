@@ -156,10 +156,20 @@ int utm_get_column(utm_ctx *ctx, int64_t global_idx, uint64_t *out);
 int utm_apply_records(utm_ctx *ctx, const utm_record *recs, int32_t n_ranks, const uint64_t *winner_col,
                       int64_t *idx, int64_t *new_count, double *score);
 
+/* ---- P2P column access (optional; utm_comm_init sets it up by itself) ---------------------------- */
+/* Every shard can map the other shards' columns (hipIpc) and read a remote winner's column in place
+ * instead of receiving it: export one blob per shard, hand all shards' blobs (rank order) to import.
+ * Afterwards utm_apply_records accepts winner_col == NULL for remote winners. */
+int utm_p2p_blob_bytes(utm_ctx *ctx, uint64_t *n_bytes);
+int utm_p2p_export(utm_ctx *ctx, void *blob);
+int utm_p2p_import(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *blobs);
+
 /* ---- RCCL (one process per GPU; ids are exchanged by the caller) ------------------------------ */
 #define UTM_UNIQUE_ID_BYTES 128
 int utm_comm_get_unique_id(void *id);
-/* After this, utm_step / utm_run exchange records + winner columns with one ncclAllGather per iteration. */
+/* After this, utm_step / utm_run are collective: one ncclAllGather of the shards' records per iteration;
+ * the winner's column is read over P2P mappings (set up here), or rides in the same all-gather when the
+ * mappings cannot be made on every rank. */
 int utm_comm_init(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *id);
 int utm_comm_allreduce_max(utm_ctx *ctx, double *value); /* in place; also a barrier */
 

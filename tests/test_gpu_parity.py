@@ -318,6 +318,45 @@ def test_rccl_single_rank_path(dev):
     assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
 
 
+def _gpu_p2p_worker(rank, world, port, q):
+    from utmos_amd.sharded import SocketTransport, enable_p2p, shard_bounds, sharded_greedy
+    transport = SocketTransport(rank, world, port=port)
+    try:
+        from utmos_amd import device
+        n_var, n_samp = 64 * 128 * 5 + 17, 64
+        cols, af = device.synth_host(6, n_var, n_samp)
+        first, n_local = shard_bounds(n_samp, rank, world)
+        with device.DeviceMatrix(n_samp, device=0, first_sample=first, n_local=n_local) as m:
+            for lo, hi in ((0, 20000), (20000, n_var)):          # two chunks: two mappings per peer
+                c = m.add_chunk(hi - lo)
+                m.synth_fill(c, seed=6, first_var_global=lo)
+                m.set_af(c, af[lo:hi].astype(np.float64) / 3.0)
+            on = enable_p2p(m, transport)
+            m.reset()
+            got = list(sharded_greedy(m, transport, n_samp))
+        exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8), af=af.astype(np.float64) / 3.0)
+        ok = on and [g[0] for g in got] == exp[0].tolist() and [g[2] for g in got] == exp[2].tolist()
+        q.put((rank, ok, len(got)))
+    finally:
+        transport.close()
+
+
+def test_p2p_winner_columns_read_in_place_across_processes(dev):
+    """Shards map each other's columns with hipIpc: the winner's column is never copied between them."""
+    import multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gpu_p2p_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res) and res[0][2] == res[1][2] == res[2][2] > 30
+
+
 def _gpu_shard_worker(rank, world, port, q):
     # no torch in a process that runs libutmos_hip.so: its wheel carries another HIP runtime
     from utmos_amd.sharded import SocketTransport

@@ -67,6 +67,9 @@ PROTOTYPES = {
     "utm_get_column": [_P, _I64, _P],
     "utm_apply_records": [_P, ctypes.POINTER(Record), _I32, _P, ctypes.POINTER(_I64), ctypes.POINTER(_I64),
                           ctypes.POINTER(ctypes.c_double)],
+    "utm_p2p_blob_bytes": [_P, ctypes.POINTER(_U64)],
+    "utm_p2p_export": [_P, _P],
+    "utm_p2p_import": [_P, _I32, _I32, _P],
     "utm_comm_get_unique_id": [_P],
     "utm_comm_init": [_P, _I32, _I32, _P],
     "utm_comm_allreduce_max": [_P, ctypes.POINTER(ctypes.c_double)],

@@ -23,6 +23,7 @@ struct IterState {
     int prev_valid;  // a winner column still has to be OR-ed into `covered`
     int prev_local;  // its local column index, or -1: take it from exchange slot prev_rank
     int prev_rank;
+    i64 prev_gidx;   // its global sample index
     unsigned n_active;  // selectable local samples = length of act[]
     unsigned best_pos;  // position in act[] of this shard's best of the current iteration
     i64 iter;           // rows produced so far
@@ -132,13 +133,23 @@ __device__ __forceinline__ i64 wave_sum_u63(u64 v)
     return (i64)(((u64)p2 << 42) + ((u64)p1 << 21) + p0);
 }
 
-// Winner column of the previous iteration for words [w0, ...) of a chunk, or nullptr.
-__device__ __forceinline__ const u64 *pending_column(const IterState *st, const u64 *cols, u64 wp, const u64 *xbuf,
-                                                     u64 slot_words, u64 chunk_off)
+// Where the winner column of the previous iteration can be read from on this shard.
+struct Pending {
+    const u64 *xbuf;               // exchange slots {record, whole column} (column all-gather form)
+    u64 slot_words;
+    u64 chunk_off;
+    const u64 *const *peer_cols;   // P2P form: this chunk's column base on every rank (IPC-mapped), or nullptr
+    const unsigned *peer_first;    // first global sample of every rank
+    int fuse;                      // scoring kernels: OR it into the covered tile while staging it
+};
+
+// Winner column of the previous iteration (base of the chunk's column), or nullptr.
+__device__ __forceinline__ const u64 *pending_column(const IterState *st, const u64 *cols, u64 wp, const Pending &p)
 {
     if (!st->prev_valid) return nullptr;
     if (st->prev_local >= 0) return cols + (u64)st->prev_local * wp;
-    return xbuf + (u64)st->prev_rank * slot_words + UTM_HDR_WORDS + chunk_off;
+    if (p.peer_cols) return p.peer_cols[st->prev_rank] + (u64)(st->prev_gidx - (i64)p.peer_first[st->prev_rank]) * wp;
+    return p.xbuf + (u64)st->prev_rank * p.slot_words + UTM_HDR_WORDS + p.chunk_off;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -152,7 +163,7 @@ __device__ __forceinline__ const u64 *pending_column(const IterState *st, const 
 // ------------------------------------------------------------------------------------------------
 template <int STEPS, bool NT>
 __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
-                                                   const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                                   const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, unsigned group_size, unsigned n_groups)
 {
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
 
     v4u *cv = reinterpret_cast<v4u *>(covered + w0);
-    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
     const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
     for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
         v4u c = cv[i];
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
 #define UTM_AF_TILE_WORDS 128
 __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const float *__restrict__ af, int e_base,
-                                                   const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                                   const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
                                                    unsigned n_groups)
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
     if (st->done) return;
     const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
     const u64 w0 = (u64)tile * UTM_AF_TILE_WORDS;
-    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
     if (threadIdx.x < UTM_AF_TILE_WORDS) {
         u64 c = covered[w0 + threadIdx.x];
         if (wcol) {
@@ -313,7 +324,7 @@ __device__ __forceinline__ u64 af_fixed(unsigned f, int e_base)
 template <int STEPS>
 __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const unsigned *__restrict__ afbits, int e_base,
-                                                   const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                                   const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
                                                    unsigned n_groups)
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
     v4u *cv = reinterpret_cast<v4u *>(covered + w0);
-    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
     const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
     for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
         v4u c = cv[i];
@@ -455,10 +466,10 @@ __global__ __launch_bounds__(64) void k_score_seq(const SeqChunk *__restrict__ c
 
 // covered |= pending winner column (used where the update is not fused into a scoring kernel)
 __global__ __launch_bounds__(256) void k_apply_pending(u64 *__restrict__ covered, const u64 *__restrict__ cols, u64 wp,
-                                                       const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                                       const Pending pend,
                                                        const IterState *__restrict__ st)
 {
-    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    const u64 *wcol = pending_column(st, cols, wp, pend);
     if (!wcol) return;
     for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) covered[w] |= wcol[w];
 }
@@ -479,12 +490,12 @@ __global__ __launch_bounds__(256) void k_or_column(u64 *__restrict__ covered, co
 // re-scoring would give.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_newly(u64 *__restrict__ covered, const u64 *__restrict__ cols, u64 wp,
-                                               const u64 *__restrict__ xbuf, u64 slot_words, u64 chunk_off,
+                                               const Pending pend,
                                                const IterState *__restrict__ st, unsigned *__restrict__ list_idx,
                                                u64 *__restrict__ list_val, unsigned *__restrict__ list_n)
 {
     if (st->done) return;
-    const u64 *wcol = pending_column(st, cols, wp, xbuf, slot_words, chunk_off);
+    const u64 *wcol = pending_column(st, cols, wp, pend);
     if (!wcol) return;
     for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) {
         const u64 c = covered[w];
@@ -755,6 +766,7 @@ __device__ void decide(const PickArgs &a)
     st->n_active_total -= 1;
     st->prev_valid = 1;
     st->prev_rank = best_rank;
+    st->prev_gidx = best.gidx;
     if (best.gidx >= (i64)a.first && best.gidx < (i64)a.first + a.n_local) {
         const unsigned loc = (unsigned)(best.gidx - a.first);
         a.state[loc] = 0;  // sample_mask[use_sample] = 0 (select.py:100)

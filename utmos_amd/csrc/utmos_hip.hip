@@ -99,6 +99,9 @@ struct Chunk {
     u64 *covered = nullptr;
     void *af = nullptr;    // device: AF in its own type (float or double), wp*64 entries: chains read this
     float *af32 = nullptr; // device: float32 AF for the parallel estimate (== af when the AF is float32)
+    int index = 0;
+    const u64 **d_peer_cols = nullptr;  // device array [n_ranks]: this chunk's column base on every rank (P2P), or null
+    std::vector<void *> ipc_opened;     // mappings to close
     unsigned *list_idx = nullptr;  // decremental scoring: words newly covered by the last winner
     u64 *list_val = nullptr;
     std::vector<float> h_af32;
@@ -163,6 +166,9 @@ struct utm_ctx {
     // RCCL
     int rank = 0, n_ranks = 1;
     ncclComm_t comm = nullptr;
+    // P2P: every rank maps every other rank's columns (hipIpc); the winner's column is then read in place
+    bool p2p = false;
+    unsigned *d_peer_first = nullptr;  // [n_ranks]
 
     // stats
     i64 score_launches = 0;
@@ -175,6 +181,20 @@ struct utm_ctx {
 };
 
 static inline u64 round_up(u64 x, u64 m) { return (x + m - 1) / m * m; }
+
+// How kernels find the previous winner's column.  With P2P the scoring kernels never fuse the update
+// (every workgroup would pull the remote tile over xGMI): k_apply_pending reads the column once instead.
+static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel)
+{
+    Pending p;
+    p.xbuf = c->d_xbuf;
+    p.slot_words = c->xbuf_slot_words;
+    p.chunk_off = ch.off;
+    p.peer_cols = c->p2p ? (const u64 *const *)ch.d_peer_cols : nullptr;
+    p.peer_first = c->d_peer_first;
+    p.fuse = scoring_kernel && !c->p2p;
+    return p;
+}
 
 extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_sample, uint32_t n_samp_local,
                               uint32_t flags, utm_ctx **out)
@@ -217,11 +237,14 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     return UTM_OK;
 }
 
+static void p2p_close(utm_ctx *c);
+
 extern "C" int utm_ctx_destroy(utm_ctx *c)
 {
     if (!c) return UTM_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    p2p_close(c);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto &ch : c->chunks) {
         (void)hipFree(ch.cols);
@@ -272,6 +295,7 @@ extern "C" int utm_add_chunk(utm_ctx *c, uint64_t n_var, int32_t *chunk)
     HIP_TRY(hipMemsetAsync(ch.cols, 0, bytes, c->stream));
     HIP_TRY(hipMalloc(&ch.covered, ch.wp * 8));
     HIP_TRY(hipMemsetAsync(ch.covered, 0, ch.wp * 8, c->stream));
+    ch.index = (int)c->chunks.size();
     c->chunks.push_back(std::move(ch));
     c->n_var_total += n_var;
     c->col_words += c->chunks.back().wp;
@@ -564,7 +588,8 @@ static int build_af_tables(utm_ctx *c)
 // ---------------------------------------------------------------------------------------- loop set-up
 static int ensure_xbuf(utm_ctx *c, int n_ranks)
 {
-    const u64 slot = (n_ranks == 1 && !c->comm) ? UTM_HDR_WORDS : c->slot_words;
+    // records only, unless whole columns travel through the slots (column all-gather / host-staged without P2P)
+    const u64 slot = ((n_ranks == 1 && !c->comm) || c->p2p) ? UTM_HDR_WORDS : c->slot_words;
     if (c->d_xbuf && c->xbuf_ranks == n_ranks && c->xbuf_slot_words == slot) return UTM_OK;
     (void)hipFree(c->d_xbuf);
     c->d_xbuf = nullptr;
@@ -692,20 +717,18 @@ static int tune_env(const char *name, int dflt)
 template <int STEPS>
 static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups, bool nt)
 {
-    const u64 slot = c->xbuf_slot_words;
     if (nt)
         hipLaunchKernelGGL((k_score_int<STEPS, true>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                           c->d_xbuf, slot, ch.off, c->d_st, c->d_act, c->d_cnt, group, n_groups);
+                           pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
     else
         hipLaunchKernelGGL((k_score_int<STEPS, false>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                           c->d_xbuf, slot, ch.off, c->d_st, c->d_act, c->d_cnt, group, n_groups);
+                           pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
 }
 
 // Enqueue the scoring of one iteration for every chunk (and the pending covered update).
 static int enqueue_score(utm_ctx *c, bool force_sequential = false)
 {
     const unsigned a_ub = std::max(1u, c->active_ub);
-    const u64 slot = c->xbuf_slot_words;
     static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
     static const int min_wgs = tune_env("UTM_MIN_WGS", 1024);
     static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
@@ -731,11 +754,16 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
         (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
         c->ev_used += 2;
     };
-    if (c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential)) {
+    const bool seq_path = c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential);
+    if (c->p2p && !seq_path)  // the scoring kernels do not fuse the update here: read the winner's column once
+        for (auto &ch : c->chunks)
+            hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                               ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
+    if (seq_path) {
         // sequential chain: update covered first, then one lane per sample over all chunks
         for (auto &ch : c->chunks)
             hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
-                               ch.covered, ch.cols, ch.wp, c->d_xbuf, slot, ch.off, c->d_st);
+                               ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
         ev_begin();
         const unsigned blocks = (a_ub + 63) / 64;
         if (c->af_mode == UTM_AF_F32)
@@ -757,7 +785,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                 unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
                 n_groups = (a_ub + group - 1) / group;
                 hipLaunchKernelGGL(k_score_afq, dim3((unsigned)(tiles * n_groups)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                                   ch.af32, 150 - c->af_q, c->d_xbuf, slot, ch.off, c->d_st, c->d_act,
+                                   ch.af32, 150 - c->af_q, pending_of(c, ch, true), c->d_st, c->d_act,
                                    c->d_cnt, c->d_afsum, group, n_groups);
             } else {
                 const u64 steps_total = ch.wp / UTM_STEP_WORDS;
@@ -778,8 +806,8 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                     const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
                     const int eb = 150 - c->af_q;
 #define UTM_LAUNCH_AFG(S)                                                                                              \
-    hipLaunchKernelGGL(k_score_afs<S>, dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb, c->d_xbuf, \
-                       slot, ch.off, c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups)
+    hipLaunchKernelGGL(k_score_afs<S>, dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb,        \
+                       pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups)
                     if (steps == 16) UTM_LAUNCH_AFG(16);
                     else if (steps == 8) UTM_LAUNCH_AFG(8);
                     else UTM_LAUNCH_AFG(2);
@@ -806,7 +834,7 @@ static int enqueue_score_decr(utm_ctx *c)
     for (size_t k = 0; k < c->chunks.size(); ++k) {
         Chunk &ch = c->chunks[k];
         hipLaunchKernelGGL(k_newly, dim3((unsigned)std::min<u64>(2048, (ch.wp + 255) / 256)), dim3(256), 0, c->stream, ch.covered,
-                           ch.cols, ch.wp, c->d_xbuf, c->xbuf_slot_words, ch.off, c->d_st, ch.list_idx, ch.list_val, c->d_listn + k);
+                           ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, ch.list_idx, ch.list_val, c->d_listn + k);
         const dim3 grid((a_ub + 3) / 4, split);
         if (af)
             hipLaunchKernelGGL(k_decr<true>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, reinterpret_cast<const unsigned *>(ch.af32),
@@ -858,8 +886,9 @@ static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
     } else {
         hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(1024), 0, c->stream, a);
         u64 *slot = c->d_xbuf + (u64)c->rank * c->xbuf_slot_words;
-        for (auto &ch : c->chunks)
-            hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+        if (!c->p2p)
+            for (auto &ch : c->chunks)
+                hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
                                slot + UTM_HDR_WORDS + ch.off, ch.cols, ch.wp, c->d_st, c->d_act);
         HIP_TRY(hipGetLastError());
         // one exchange per iteration: every shard's {record, candidate column}, in place
@@ -1007,10 +1036,9 @@ extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
 
 static int flush_pending(utm_ctx *c)
 {
-    const u64 slot = c->xbuf_slot_words;
     for (auto &ch : c->chunks)
         hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
-                           ch.covered, ch.cols, ch.wp, c->d_xbuf, slot, ch.off, c->d_st);
+                           ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
     HIP_TRY(hipGetLastError());
     return UTM_OK;
 }
@@ -1126,10 +1154,10 @@ extern "C" int utm_apply_records(utm_ctx *c, const utm_record *recs, int32_t n_r
     }
     for (int r = 0; r < n_ranks; ++r)
         HIP_TRY(hipMemcpyAsync(c->d_xbuf + (u64)r * slot, &recs[r], sizeof(utm_record), hipMemcpyHostToDevice, c->stream));
-    if (win >= 0 && winner_col) {
+    if (win >= 0 && winner_col && !c->p2p) {
         if (n_ranks == 1) return fail(UTM_EINVAL, "winner_col given for a single shard");
         HIP_TRY(hipMemcpyAsync(c->d_xbuf + (u64)win * slot + UTM_HDR_WORDS, winner_col, c->col_words * 8, hipMemcpyHostToDevice, c->stream));
-    } else if (win >= 0) {
+    } else if (win >= 0 && !c->p2p) {
         const i64 g = recs[win].idx;
         if (g < (i64)c->first || g >= (i64)c->first + c->n_local) return fail(UTM_EINVAL, "winner %lld is remote but winner_col is NULL", (long long)g);
     }
@@ -1147,6 +1175,79 @@ extern "C" int utm_apply_records(utm_ctx *c, const utm_record *recs, int32_t n_r
     if (idx) *idx = i;
     if (new_count) *new_count = n;
     if (score) *score = s;
+    return UTM_OK;
+}
+
+// ---------------------------------------------------------------------------------------- P2P column access
+struct P2PHeader {
+    uint32_t first, n_local, n_chunks, pad;
+};
+
+extern "C" int utm_p2p_blob_bytes(utm_ctx *c, uint64_t *n_bytes)
+{
+    CTX(c);
+    if (!n_bytes) return fail(UTM_EINVAL, "n_bytes is NULL");
+    *n_bytes = sizeof(P2PHeader) + c->chunks.size() * sizeof(hipIpcMemHandle_t);
+    return UTM_OK;
+}
+
+extern "C" int utm_p2p_export(utm_ctx *c, void *blob)
+{
+    CTX(c);
+    if (!blob) return fail(UTM_EINVAL, "blob is NULL");
+    if (c->chunks.empty()) return fail(UTM_ESTATE, "no chunks");
+    P2PHeader hd{c->first, c->n_local, (uint32_t)c->chunks.size(), 0};
+    memcpy(blob, &hd, sizeof hd);
+    hipIpcMemHandle_t *hs = reinterpret_cast<hipIpcMemHandle_t *>(static_cast<char *>(blob) + sizeof hd);
+    for (size_t k = 0; k < c->chunks.size(); ++k) HIP_TRY(hipIpcGetMemHandle(&hs[k], c->chunks[k].cols));
+    return UTM_OK;
+}
+
+static void p2p_close(utm_ctx *c)
+{
+    for (auto &ch : c->chunks) {
+        for (void *p : ch.ipc_opened) (void)hipIpcCloseMemHandle(p);
+        ch.ipc_opened.clear();
+        (void)hipFree(ch.d_peer_cols);
+        ch.d_peer_cols = nullptr;
+    }
+    (void)hipFree(c->d_peer_first);
+    c->d_peer_first = nullptr;
+    c->p2p = false;
+}
+
+extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const void *blobs)
+{
+    CTX(c);
+    if (!blobs || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(UTM_EINVAL, "bad rank %d of %d", rank, n_ranks);
+    p2p_close(c);
+    const size_t blob = sizeof(P2PHeader) + c->chunks.size() * sizeof(hipIpcMemHandle_t);
+    std::vector<unsigned> firsts(n_ranks);
+    std::vector<std::vector<const u64 *>> table(c->chunks.size(), std::vector<const u64 *>(n_ranks, nullptr));
+    for (int r = 0; r < n_ranks; ++r) {
+        const char *b = static_cast<const char *>(blobs) + (size_t)r * blob;
+        P2PHeader hd;
+        memcpy(&hd, b, sizeof hd);
+        if (hd.n_chunks != c->chunks.size()) { p2p_close(c); return fail(UTM_EINVAL, "rank %d has %u chunks, this one %zu", r, hd.n_chunks, c->chunks.size()); }
+        firsts[r] = hd.first;
+        const hipIpcMemHandle_t *hs = reinterpret_cast<const hipIpcMemHandle_t *>(b + sizeof hd);
+        for (size_t k = 0; k < c->chunks.size(); ++k) {
+            if (r == rank) { table[k][r] = c->chunks[k].cols; continue; }
+            void *p = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&p, hs[k], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { p2p_close(c); return fail(UTM_EHIP, "hipIpcOpenMemHandle(rank %d, chunk %zu) -> %s", r, k, hipGetErrorString(e)); }
+            c->chunks[k].ipc_opened.push_back(p);
+            table[k][r] = static_cast<const u64 *>(p);
+        }
+    }
+    HIP_TRY(hipMalloc(&c->d_peer_first, (size_t)n_ranks * 4));
+    HIP_TRY(hipMemcpy(c->d_peer_first, firsts.data(), (size_t)n_ranks * 4, hipMemcpyHostToDevice));
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        HIP_TRY(hipMalloc(&c->chunks[k].d_peer_cols, (size_t)n_ranks * sizeof(u64 *)));
+        HIP_TRY(hipMemcpy(c->chunks[k].d_peer_cols, table[k].data(), (size_t)n_ranks * sizeof(u64 *), hipMemcpyHostToDevice));
+    }
+    c->p2p = true;
+    c->prepared = false;  // exchange slots shrink to records
     return UTM_OK;
 }
 
@@ -1174,7 +1275,27 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
     NCCL_TRY(g_rccl.CommInitRank(&c->comm, n_ranks, u, rank));
     c->rank = rank;
     c->n_ranks = n_ranks;
-    TRY(ensure_xbuf(c, n_ranks));  // c->comm is set: slots carry whole columns
+    // Map every rank's columns (hipIpc) so that a winner's column is read in place over xGMI instead of
+    // travelling through an all-gather; all ranks must agree, otherwise everyone keeps the all-gather form.
+    if (n_ranks > 1 && !tune_env("UTM_NO_P2P", 0)) {
+        uint64_t blob = 0;
+        TRY(utm_p2p_blob_bytes(c, &blob));
+        std::vector<char> mine(blob), all(blob * n_ranks);
+        int ok = utm_p2p_export(c, mine.data()) == UTM_OK;
+        char *d_all = nullptr;
+        HIP_TRY(hipMalloc(&d_all, blob * n_ranks));
+        HIP_TRY(hipMemcpy(d_all + blob * rank, mine.data(), blob, hipMemcpyHostToDevice));
+        NCCL_TRY(g_rccl.AllGather(d_all + blob * rank, d_all, blob, ncclChar, c->comm, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(all.data(), d_all, blob * n_ranks, hipMemcpyDeviceToHost));
+        (void)hipFree(d_all);
+        if (ok) ok = utm_p2p_import(c, rank, n_ranks, all.data()) == UTM_OK;
+        double flag = ok ? 1.0 : 0.0, neg = -flag;   // min over ranks = -max(-flag)
+        TRY(utm_comm_allreduce_max(c, &neg));
+        (void)flag;
+        if (-neg < 0.5 && c->p2p) p2p_close(c);
+    }
+    TRY(ensure_xbuf(c, n_ranks));  // c->comm is set: slots carry whole columns unless P2P is on
     c->prepared = false;
     return UTM_OK;
 }

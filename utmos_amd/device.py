@@ -22,6 +22,7 @@ class DeviceMatrix:
         self.first_sample = int(first_sample)
         self.n_local = int(self.n_samples - self.first_sample if n_local is None else n_local)
         self.chunk_vars = []
+        self.p2p = False
         flags = (nat.FLAG_PROFILE_EVENTS if profile_events else 0) | (nat.FLAG_AF_SEQUENTIAL if af_sequential else 0)
         code = nat.lib().utm_ctx_create(int(device), self.n_samples, self.first_sample, self.n_local, flags,
                                         ctypes.byref(self._h))
@@ -187,6 +188,21 @@ class DeviceMatrix:
         nat.check(nat.lib().utm_apply_records(self._h, arr, len(records), _ptr(col), ctypes.byref(i),
                                               ctypes.byref(n), ctypes.byref(s)))
         return None if i.value < 0 else (i.value, n.value, s.value)
+
+    # -- P2P column access between shards (hipIpc)
+    def p2p_export(self):
+        n = ctypes.c_uint64()
+        nat.check(nat.lib().utm_p2p_blob_bytes(self._h, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        nat.check(nat.lib().utm_p2p_export(self._h, buf))
+        return buf.raw
+
+    def p2p_import(self, rank, blobs):
+        """blobs: every shard's p2p_export() in rank order.  Remote winners are then read in place."""
+        joined = b"".join(blobs)
+        buf = ctypes.create_string_buffer(joined, len(joined))
+        nat.check(nat.lib().utm_p2p_import(self._h, int(rank), len(blobs), buf))
+        self.p2p = True
 
     # -- RCCL
     @staticmethod

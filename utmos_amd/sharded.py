@@ -118,6 +118,20 @@ class SocketTransport:
             blob = self._recv(self.peers[0], pack.size * self.world)
         return [pack.unpack_from(blob, r * pack.size) for r in range(self.world)]
 
+    def allgather_bytes(self, blob):
+        """Equal-sized byte strings from every rank, in rank order."""
+        if self.world == 1:
+            return [blob]
+        n = len(blob)
+        if self.rank == 0:
+            parts = [blob] + [self._recv(c, n) for c in self.peers]
+            for c in self.peers:
+                c.sendall(b"".join(parts))
+            return parts
+        self.peers[0].sendall(blob)
+        data = self._recv(self.peers[0], n * self.world)
+        return [data[i * n:(i + 1) * n] for i in range(self.world)]
+
     def broadcast(self, column, n_words, src):
         n = n_words * 8
         if self.rank == 0:
@@ -172,19 +186,42 @@ def rendezvous_unique_id(rank, make_id, timeout=300.0):
     raise RuntimeError(f"rank {rank}: no ncclUniqueId at {path} after {timeout:.0f} s")
 
 
+def enable_p2p(shard, transport):
+    """Map every shard's columns into every other shard (hipIpc).  Collective; returns True when all succeed."""
+    if transport.world == 1:
+        return False
+    try:
+        blob = shard.p2p_export()
+    except Exception:  # noqa: BLE001 - any failure means "no P2P here"
+        blob = None
+    size = max(transport.allgather((0.0, -1 if blob is None else len(blob), 0)), key=lambda r: r[1])[1]
+    blobs = transport.allgather_bytes(blob if blob is not None else bytes(max(size, 1)))
+    ok = blob is not None
+    if ok:
+        try:
+            shard.p2p_import(transport.rank, blobs)
+        except Exception:  # noqa: BLE001
+            ok = False
+    everyone = all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0)))
+    if not everyone:
+        shard.p2p = False   # (a context that imported keeps its mappings but columns are broadcast again)
+    return everyone
+
+
 def sharded_greedy(shard, transport, select_count):
     """Yield (global idx, new_count, score) per selected sample; identical on every rank.
 
     `shard` is this rank's matrix (DeviceMatrix with first_sample/n_local set, state and weights
     already applied, reset done)."""
     n_words = shard.column_words()
+    p2p = getattr(shard, "p2p", False)   # remote winners' columns are read in place: nothing to broadcast
     for _ in range(int(select_count)):
         records = transport.allgather(shard.local_best())
         owner = pick_winner(records)
         if owner is None:
             return
         column = None
-        if transport.world > 1:
+        if transport.world > 1 and not p2p:
             mine = shard.get_column(records[owner][1]) if transport.rank == owner else None
             column = transport.broadcast(mine, n_words, owner)
         out = shard.apply_records(records, None if transport.rank == owner else column)
