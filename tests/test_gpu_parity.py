@@ -439,3 +439,51 @@ def test_decremental_survives_peek_and_covered_reads(dev):
             m.peek_scores()            # applies the pending winner outside the loop: next pass must be a full one
             m.covered(0)
         assert got_idx == exp[0][:len(got_idx)].tolist()
+
+
+def test_parity_at_production_tile_sizes(dev):
+    """2M variants x 2,504 samples (the BASELINE sample count, full 32 KiB tiles, ~24k workgroups per
+    launch): first iterations of the integer and float32-AF loops against the OpenMP C oracle on the
+    matrix downloaded from the device."""
+    n_var, n_samp, k = 2_000_000, 2504, 24
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.synth_fill(c, seed=9)
+        cols = m.download_columns(c)
+        _, af = dev.synth_host(9, n_var, n_samp, want_cols=False)
+        state = np.ones(n_samp, np.uint8)
+        state[100:110] = 2
+        m.set_state(state)
+        got = m.run(k)
+        exp = ou.c_greedy(cols, n_var, state, k_max=k, omp=True)
+        assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+        m.set_af(c, af)
+        m.reset()
+        got = m.run(k)
+        exp = ou.c_greedy(cols, n_var, state, af=af, k_max=k, omp=True)
+        assert got[0].tolist() == exp[0].tolist() and got[2].tolist() == exp[2].tolist()
+
+
+@pytest.mark.parametrize("decremental", [False, True])
+def test_full_size_select_all_invariants(dev, decremental):
+    """BASELINE configs[1] in full (10M x 2,504, select all): size-independent properties of a greedy
+    maximum-coverage run -- every sample exactly once, gains never grow, everything captured exactly at
+    the end, per-sample gain bounded by its carrier total -- and brute force == decremental."""
+    n_var, n_samp = 10_000_000, 2504
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.synth_fill(c, seed=0)
+        var_count = m.var_count()
+        if decremental:
+            m.set_decremental(True)
+        idx, new, score = m.run(n_samp)
+        assert len(idx) == n_samp and sorted(idx.tolist()) == list(range(n_samp))
+        assert (np.diff(new) <= 0).all()                    # submodularity: marginal gains are non-increasing
+        assert int(new.sum()) == n_var                      # every variant has a carrier, all get captured
+        assert (new <= var_count[idx]).all() and new[0] == var_count.max()
+        assert (score == new).all()
+        test_full_size_select_all_invariants.rows = getattr(test_full_size_select_all_invariants, "rows", {})
+        test_full_size_select_all_invariants.rows[decremental] = (idx.tolist(), new.tolist())
+    rows = test_full_size_select_all_invariants.rows
+    if len(rows) == 2:
+        assert rows[False] == rows[True]

@@ -181,6 +181,11 @@ struct utm_ctx {
 };
 
 static inline u64 round_up(u64 x, u64 m) { return (x + m - 1) / m * m; }
+static int tune_env_early(const char *name)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : 0;
+}
 
 // How kernels find the previous winner's column.  With P2P the scoring kernels never fuse the update
 // (every workgroup would pull the remote tile over xGMI): k_apply_pending reads the column once instead.
@@ -192,7 +197,8 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
     p.chunk_off = ch.off;
     p.peer_cols = c->p2p ? (const u64 *const *)ch.d_peer_cols : nullptr;
     p.peer_first = c->d_peer_first;
-    p.fuse = scoring_kernel && !c->p2p;
+    static const int no_fuse = tune_env_early("UTM_NO_FUSE");
+    p.fuse = scoring_kernel && !c->p2p && !no_fuse;
     return p;
 }
 
@@ -715,14 +721,23 @@ static int tune_env(const char *name, int dflt)
 }
 
 template <int STEPS>
-static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups, bool nt)
+static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups, bool nt, int waves)
 {
-    if (nt)
-        hipLaunchKernelGGL((k_score_int<STEPS, true>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                           pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
-    else
-        hipLaunchKernelGGL((k_score_int<STEPS, false>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                           pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
+#define UTM_LAUNCH_INT(NT, W, P)                                                                                           \
+    hipLaunchKernelGGL((k_score_int<STEPS, NT, W, P>), dim3(blocks), dim3(W * 64), 0, c->stream, ch.cols, ch.covered, ch.wp,   \
+                       pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups)
+    static const int pipe = tune_env("UTM_INT_PIPE", 0);
+    if (waves == 8) {
+        if (nt) UTM_LAUNCH_INT(true, 8, false);
+        else UTM_LAUNCH_INT(false, 8, false);
+    } else if (pipe) {
+        if (nt) UTM_LAUNCH_INT(true, 4, true);
+        else UTM_LAUNCH_INT(false, 4, true);
+    } else {
+        if (nt) UTM_LAUNCH_INT(true, 4, false);
+        else UTM_LAUNCH_INT(false, 4, false);
+    }
+#undef UTM_LAUNCH_INT
 }
 
 // Enqueue the scoring of one iteration for every chunk (and the pending covered update).
@@ -755,7 +770,8 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
         c->ev_used += 2;
     };
     const bool seq_path = c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential);
-    if (c->p2p && !seq_path)  // the scoring kernels do not fuse the update here: read the winner's column once
+    static const int no_fuse = tune_env_early("UTM_NO_FUSE");
+    if ((c->p2p || no_fuse) && !seq_path)  // the scoring kernels do not fuse the update here: read the winner's column once
         for (auto &ch : c->chunks)
             hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
                                ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
@@ -798,8 +814,10 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                 }
                 if (c->af_mode == UTM_AF_NONE && (force_steps == 32 || force_steps == 8 || force_steps == 2)) steps = force_steps;
                 const u64 tiles = (steps_total + steps - 1) / steps;
+                static const int int_waves = tune_env("UTM_INT_WAVES", 4) == 8 ? 8 : 4;
+                const int waves = c->af_mode == UTM_AF_NONE ? int_waves : 4;
                 u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
-                group = std::max<u64>(4, (group + 3) / 4 * 4);
+                group = std::max<u64>(waves, (group + waves - 1) / waves * waves);
                 const unsigned n_groups = (unsigned)((a_ub + group - 1) / group);
                 const unsigned blocks = (unsigned)(tiles * n_groups);
                 if (c->af_mode != UTM_AF_NONE) {
@@ -812,9 +830,9 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                     else if (steps == 8) UTM_LAUNCH_AFG(8);
                     else UTM_LAUNCH_AFG(2);
 #undef UTM_LAUNCH_AFG
-                } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
-                else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
-                else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+                } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt, waves);
+                else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt, waves);
+                else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt, waves);
             }
             ev_end();
             c->score_launches += 1;
