@@ -343,13 +343,13 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 // tile).  The host switches from k_score_afq to this kernel when the captured fraction passes
 // UTM_AF_SWITCH.  Same integer sums, same exactness argument.
 // ------------------------------------------------------------------------------------------------
-#define UTM_AFQ_CAP 1024  // queue entries per wave
+// queue entries per wave: STEPS KiB of ~covered + 4 queues must leave room for 4-5 workgroups per CU
 __device__ __forceinline__ u64 af_fixed(unsigned f, int e_base)
 {
     return (u64)((f & 0x7FFFFFu) | 0x800000u) << ((f >> 23) - e_base);
 }
 
-template <int STEPS>
+template <int STEPS, int CAP>
 __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const unsigned *__restrict__ afbits, int e_base,
                                                    const Pending pend,
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
                                                    unsigned n_groups)
 {
     __shared__ v4u live[STEPS * 64];
-    __shared__ unsigned queue[4][UTM_AFQ_CAP];
+    __shared__ unsigned queue[4][CAP];
     if (st->done) return;
     const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
     const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
@@ -410,9 +410,9 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
             if (__ballot(nb != 0) == 0) continue;  // nothing survived in these 8 KiB
             const unsigned incl = wave_scan_incl_u32(nb);
             const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-            if (qn + total > UTM_AFQ_CAP) drain();
+            if (qn + total > CAP) drain();
             const unsigned base = (unsigned)(j0 * UTM_STEP_WORDS + 2 * lane) * 64;  // variant offset inside the tile
-            if (total <= UTM_AFQ_CAP) {
+            if (total <= CAP) {
                 unsigned pos = qn + incl - nb;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {

@@ -807,7 +807,8 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                 const u64 steps_total = ch.wp / UTM_STEP_WORDS;
                 const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
                 int steps = 2;
-                const int big = c->af_mode != UTM_AF_NONE ? 16 : 32;  // the AF kernel shares LDS with its bit queues
+                static const int af_big = tune_env("UTM_AF_STEPS", 16) == 32 ? 32 : 16;
+                const int big = c->af_mode != UTM_AF_NONE ? af_big : 32;  // the AF kernel shares LDS with its bit queues
                 for (int cand : {big, 8}) {
                     const u64 tiles = (steps_total + cand - 1) / cand;
                     if (tiles * waves_needed >= (u64)min_wgs) { steps = cand; break; }
@@ -823,12 +824,13 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                 if (c->af_mode != UTM_AF_NONE) {
                     const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
                     const int eb = 150 - c->af_q;
-#define UTM_LAUNCH_AFG(S)                                                                                              \
-    hipLaunchKernelGGL(k_score_afs<S>, dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb,        \
+#define UTM_LAUNCH_AFG(S, Q)                                                                                              \
+    hipLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb,   \
                        pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups)
-                    if (steps == 16) UTM_LAUNCH_AFG(16);
-                    else if (steps == 8) UTM_LAUNCH_AFG(8);
-                    else UTM_LAUNCH_AFG(2);
+                    if (steps == 32) UTM_LAUNCH_AFG(32, 512);
+                    else if (steps == 16) UTM_LAUNCH_AFG(16, 1024);
+                    else if (steps == 8) UTM_LAUNCH_AFG(8, 1024);
+                    else UTM_LAUNCH_AFG(2, 1024);
 #undef UTM_LAUNCH_AFG
                 } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt, waves);
                 else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt, waves);
