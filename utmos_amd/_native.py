@@ -86,6 +86,9 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C utmos_amd/csrc` (hipcc, --offload-arch=gfx950).  utmos_amd has no CPU fallback.")
+        # dmabuf IPC is the only IPC mode this host driver supports (RCCL, hipIpc mappings between shards);
+        # must be in the environment before the HIP runtime initialises
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         handle = ctypes.CDLL(LIB_PATH)
         handle.utm_last_error.restype = ctypes.c_char_p
         handle.utm_last_error.argtypes = []
