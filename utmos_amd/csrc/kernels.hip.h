@@ -667,17 +667,112 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
 // The reference's chain for ONE candidate per workgroup: 1024 lanes compact the AF values of the
 // candidate's surviving bits, in ascending variant order, into LDS (popcount -> block prefix sum ->
 // scatter); lane 0 then adds them one by one in float64.  Only the additions are serial.
+// Fast path of the chains (sparse candidates, i.e. almost every iteration after the first few): the
+// candidate's column is cut into segments of 4096 words; k_chain_fill lets one workgroup per
+// (segment, candidate) compact the AF values of the surviving bits, in order, into a global buffer;
+// k_chain's wave 0 then only walks the per-segment counts and adds the values in order.  A segment
+// with more than UTM_SEG_CAP values, or more than UTM_FAST_CAND candidates, leaves the candidate to
+// the one-workgroup chain below.
+#define UTM_FAST_CAND 8
+#define UTM_SEG_CAP 1024
+#define UTM_SEG_WORDS 4096
+struct ChainSeg {
+    int chunk;
+    u64 w0;
+};
+struct ChainFast {
+    const ChainSeg *segs;
+    int n_segs;
+    unsigned *counts;  // [UTM_FAST_CAND][n_segs]; 0xFFFFFFFF = segment too dense
+    double *vals;      // [UTM_FAST_CAND][n_segs][UTM_SEG_CAP]
+};
+
+template <typename AF_T>
+__global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict__ chunks, const IterState *__restrict__ st,
+                                                     const CandBuf *__restrict__ cand, ChainFast f)
+{
+    __shared__ unsigned wtot[16];
+    if (st->done || !st->need_chain || st->cand_overflow || st->n_cand > UTM_FAST_CAND || (int)blockIdx.y >= st->n_cand) return;
+    const ChainSeg sg = f.segs[blockIdx.x];
+    const SeqChunk ch = chunks[sg.chunk];
+    const unsigned s = cand->samp[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 *col = ch.cols + (u64)s * ch.wp;
+    const AF_T *af = static_cast<const AF_T *>(ch.af);
+    const u64 w = sg.w0 + (u64)tid * 4;
+    u64 x[4];
+    unsigned n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = w + k < ch.w ? (col[w + k] & ~ch.covered[w + k]) : 0;
+        n += __popcll(x[k]);
+    }
+    const unsigned incl = wave_scan_incl_u32(n);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const unsigned t = wtot[k];
+        woff += k < wave ? t : 0;
+        total += t;
+    }
+    const size_t slot = (size_t)blockIdx.y * f.n_segs + blockIdx.x;
+    if (tid == 0) f.counts[slot] = total <= UTM_SEG_CAP ? total : 0xFFFFFFFFu;
+    if (total == 0 || total > UTM_SEG_CAP) return;
+    double *out = f.vals + slot * UTM_SEG_CAP + (woff + incl - n);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u64 y = x[k];
+        while (y) {
+            const int b = __builtin_ctzll(y);
+            y &= y - 1;
+            *out++ = (double)af[(w + k) * 64 + b];
+        }
+    }
+}
+
 #define UTM_CHAIN_CAP 2048
 #define UTM_CHAIN_WPT 4  // consecutive words per lane and round: 4096 words (262,144 variants) per round
 template <typename AF_T>
 __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chunks, int n_chunks,
-                                                const IterState *__restrict__ st, CandBuf *__restrict__ cand)
+                                                const IterState *__restrict__ st, CandBuf *__restrict__ cand, ChainFast f)
 {
     __shared__ double buf[UTM_CHAIN_CAP];
     __shared__ unsigned wtot[2][16];  // double buffered: one barrier per empty round
+    __shared__ int dense;
     if (st->done || !st->need_chain || st->cand_overflow || (int)blockIdx.x >= st->n_cand) return;
     const unsigned s = cand->samp[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (f.counts && st->n_cand <= UTM_FAST_CAND) {
+        // fast path: k_chain_fill compacted this candidate's values per segment; are all segments usable?
+        const unsigned *cnts = f.counts + (size_t)blockIdx.x * f.n_segs;
+        if (tid == 0) dense = 0;
+        __syncthreads();
+        for (int g = tid; g < f.n_segs; g += 1024)
+            if (cnts[g] == 0xFFFFFFFFu) dense = 1;
+        __syncthreads();
+        if (!dense) {
+            if (tid == 0) {
+                double acc = 0.0;
+                const double *vals = f.vals + (size_t)blockIdx.x * f.n_segs * UTM_SEG_CAP;
+                for (int g = 0; g < f.n_segs; ++g) {
+                    const unsigned m = cnts[g];
+                    const double *v = vals + (size_t)g * UTM_SEG_CAP;
+                    unsigned t = 0;
+                    for (; t + 8 <= m; t += 8) {
+                        const double v0 = v[t], v1 = v[t + 1], v2 = v[t + 2], v3 = v[t + 3];
+                        const double v4 = v[t + 4], v5 = v[t + 5], v6 = v[t + 6], v7 = v[t + 7];
+                        acc += v0; acc += v1; acc += v2; acc += v3;
+                        acc += v4; acc += v5; acc += v6; acc += v7;
+                    }
+                    for (; t < m; ++t) acc += v[t];
+                }
+                cand->val[blockIdx.x] = acc;
+            }
+            return;
+        }
+    }
     double acc = 0.0;
     unsigned round = 0;
     for (int c = 0; c < n_chunks; ++c) {

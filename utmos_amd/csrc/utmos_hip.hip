@@ -133,6 +133,8 @@ struct utm_ctx {
     u64 xbuf_slot_words = UTM_HDR_WORDS;  // slot size the buffer was allocated for
     SeqChunk *d_seq = nullptr;
     CandBuf *d_cand = nullptr;
+    ChainFast chain_fast{nullptr, 0, nullptr, nullptr};  // device buffers of the chains' fast path
+    ChainSeg *d_segs = nullptr;
     u64 *d_cnt_keep = nullptr;   // persistent per-sample counts (mirror of the last full scoring, then decremented)
     i64 *d_afsum_keep = nullptr;
     unsigned *d_listn = nullptr; // per chunk
@@ -261,6 +263,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
         (void)hipFree(ch.list_val);
     }
     (void)hipFree(c->d_cand);
+    (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
@@ -587,6 +590,24 @@ static int build_af_tables(utm_ctx *c)
     }
     HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
     HIP_TRY(hipMemcpy(c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
+    // segment table + buffers of the chains' fast path
+    (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
+    c->d_segs = nullptr;
+    c->chain_fast = ChainFast{nullptr, 0, nullptr, nullptr};
+    if (c->af_fixed) {
+        std::vector<ChainSeg> segs;
+        for (size_t k = 0; k < c->chunks.size(); ++k)
+            for (u64 w0 = 0; w0 < c->chunks[k].w; w0 += UTM_SEG_WORDS) segs.push_back(ChainSeg{(int)k, w0});
+        const size_t n = segs.size();
+        if (n * UTM_FAST_CAND * UTM_SEG_CAP * 8 <= (4ull << 30)) {  // keep the scratch within 4 GiB
+            HIP_TRY(hipMalloc(&c->d_segs, n * sizeof(ChainSeg)));
+            HIP_TRY(hipMemcpy(c->d_segs, segs.data(), n * sizeof(ChainSeg), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&c->chain_fast.counts, n * UTM_FAST_CAND * 4));
+            HIP_TRY(hipMalloc(&c->chain_fast.vals, n * UTM_FAST_CAND * UTM_SEG_CAP * 8));
+            c->chain_fast.segs = c->d_segs;
+            c->chain_fast.n_segs = (int)n;
+        }
+    }
     c->dirty_tables = false;
     return UTM_OK;
 }
@@ -886,12 +907,17 @@ static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
     if (!a.cand) return;
     hipLaunchKernelGGL(k_cand, dim3(1), dim3(256), 0, c->stream, a);
     const unsigned blocks = (std::max(1u, c->active_ub) + 63) / 64;
+    const ChainFast &cf = c->chain_fast;
     if (c->af_mode == UTM_AF_F32) {
-        hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand);
+        if (cf.counts)
+            hipLaunchKernelGGL(k_chain_fill<float>, dim3(cf.n_segs, UTM_FAST_CAND), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
+        hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand, cf);
         hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
                            c->d_act, c->d_cnt, c->d_fscore, 1);
     } else {
-        hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand);
+        if (cf.counts)
+            hipLaunchKernelGGL(k_chain_fill<double>, dim3(cf.n_segs, UTM_FAST_CAND), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
+        hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand, cf);
         hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
                            c->d_act, c->d_cnt, c->d_fscore, 1);
     }
