@@ -335,8 +335,12 @@ def _gpu_p2p_worker(rank, world, port, q):
             m.reset()
             got = list(sharded_greedy(m, transport, n_samp))
         exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8), af=af.astype(np.float64) / 3.0)
-        ok = on and [g[0] for g in got] == exp[0].tolist() and [g[2] for g in got] == exp[2].tolist()
-        q.put((rank, ok, len(got)))
+        idx_ok = [g[0] for g in got] == exp[0].tolist()
+        score_ok = [g[2] for g in got] == exp[2].tolist()
+        first_bad = next((i for i, (g, e) in enumerate(zip(got, exp[0].tolist())) if g[0] != e), -1)
+        q.put((rank, on and idx_ok and score_ok, len(got), f"p2p={on} idx_ok={idx_ok} score_ok={score_ok} first_bad={first_bad} exp_len={len(exp[0])}"))
+    except BaseException as e:  # noqa: BLE001
+        q.put((rank, False, 0, repr(e)))
     finally:
         transport.close()
 
@@ -354,7 +358,7 @@ def test_p2p_winner_columns_read_in_place_across_processes(dev):
     res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert all(r[1] for r in res) and res[0][2] == res[1][2] == res[2][2] > 30
+    assert all(r[1] for r in res) and res[0][2] == res[1][2] == res[2][2] > 30, res
 
 
 def _gpu_shard_worker(rank, world, port, q):

@@ -152,6 +152,23 @@ __device__ __forceinline__ const u64 *pending_column(const IterState *st, const 
     return p.xbuf + (u64)st->prev_rank * p.slot_words + UTM_HDR_WORDS + p.chunk_off;
 }
 
+// XCD-aware block -> (tile, group) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+// b + 8 share one; each XCD has its own L2).  The (tile, group) units are numbered tile-major and cut into
+// 8 equal contiguous ranges, one per XCD: an XCD walks whole variant tiles (all sample groups of a tile one
+// after the other), so a tile's ~covered words and the pending winner's words are fetched into ONE L2 and
+// reused there, while every XCD still gets the same number of units.  Grid = 8 * ceil(units / 8); surplus
+// blocks return.  Only speed depends on the placement, never results.
+__device__ __forceinline__ bool tile_of_block(u64 wp, unsigned tile_words, unsigned n_groups, unsigned &tile, unsigned &grp)
+{
+    const unsigned n_tiles = (unsigned)((wp + tile_words - 1) / tile_words);
+    const unsigned units = n_tiles * n_groups, per_xcd = (units + 7) / 8;
+    const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const unsigned u = xcd * per_xcd + j;
+    tile = u / n_groups;
+    grp = u % n_groups;
+    return j < per_xcd && u < units;
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1: integer scores.  count[s] += popcount(col_s & ~covered) over one tile of the variant axis,
 // for one group of selectable samples (calculate_scores' row loop, select.py:37-41, as a bitset
@@ -169,7 +186,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_int(const u64 *__restrict_
 {
     __shared__ v4u live[STEPS * 64];  // ~covered of this tile, STEPS KiB
     if (st->done) return;
-    const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    unsigned tile, grp;
+    if (!tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp)) return;
     const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
@@ -270,7 +288,8 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
     __shared__ unsigned aft[UTM_AF_TILE_WORDS * 64];  // float32 bit patterns
     __shared__ u64 live[UTM_AF_TILE_WORDS];
     if (st->done) return;
-    const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    unsigned tile, grp;
+    if (!tile_of_block(wp, UTM_AF_TILE_WORDS, n_groups, tile, grp)) return;
     const u64 w0 = (u64)tile * UTM_AF_TILE_WORDS;
     const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
     if (threadIdx.x < UTM_AF_TILE_WORDS) {
@@ -360,7 +379,8 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
     __shared__ v4u live[STEPS * 64];
     __shared__ unsigned queue[4][CAP];
     if (st->done) return;
-    const unsigned tile = blockIdx.x / n_groups, grp = blockIdx.x % n_groups;
+    unsigned tile, grp;
+    if (!tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp)) return;
     const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
@@ -499,7 +519,10 @@ __global__ __launch_bounds__(256) void k_apply_pending(u64 *__restrict__ covered
 {
     const u64 *wcol = pending_column(st, cols, wp, pend);
     if (!wcol) return;
-    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) covered[w] |= wcol[w];
+    // the column may live in another process / on another GPU (hipIpc mapping): system-scope loads, so that
+    // no cache of this GPU can answer with an older copy of those addresses
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256)
+        covered[w] |= __hip_atomic_load(&wcol[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // covered |= cols[col]  (utm_reset: samples that start out "used")
@@ -527,7 +550,7 @@ __global__ __launch_bounds__(256) void k_newly(u64 *__restrict__ covered, const 
     if (!wcol) return;
     for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) {
         const u64 c = covered[w];
-        const u64 x = wcol[w] & ~c;
+        const u64 x = __hip_atomic_load(&wcol[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & ~c;
         if (x) {
             const unsigned slot = atomicAdd(list_n, 1u);
             list_idx[slot] = (unsigned)w;

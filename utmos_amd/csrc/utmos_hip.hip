@@ -277,6 +277,14 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     return UTM_OK;
 }
 
+// Blocking copy ON THE CONTEXT'S STREAM.  The stream is non-blocking, so null-stream calls (hipMemcpy, hipMemset)
+// are not ordered with the kernels launched on it; every transfer goes through here instead.
+static hipError_t copy_sync(utm_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+    return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
+}
+
 #define CTX(c)                                        \
     if (!(c)) return fail(UTM_EINVAL, "ctx is NULL"); \
     HIP_TRY(hipSetDevice((c)->device))
@@ -394,7 +402,7 @@ extern "C" int utm_var_count(utm_ctx *c, int64_t *out)
     CTX(c);
     if (!out) return fail(UTM_EINVAL, "out is NULL");
     TRY(ensure_var_count(c));
-    HIP_TRY(hipMemcpy(out, c->d_varcount, (size_t)c->n_local * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(c, out, c->d_varcount, (size_t)c->n_local * 8, hipMemcpyDeviceToHost));
     return UTM_OK;
 }
 
@@ -470,7 +478,7 @@ extern "C" int utm_set_weights(utm_ctx *c, const double *w)
     for (uint32_t s = 0; s < c->n_total; ++s)
         if (!isfinite(w[s])) return fail(UTM_EINVAL, "weights[%u] is not finite", s);
     if (!c->d_weights) HIP_TRY(hipMalloc(&c->d_weights, (size_t)c->n_total * 8));
-    HIP_TRY(hipMemcpy(c->d_weights, w, (size_t)c->n_total * 8, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_weights, w, (size_t)c->n_total * 8, hipMemcpyHostToDevice));
     c->have_weights = true;
     return UTM_OK;
 }
@@ -509,7 +517,7 @@ extern "C" int utm_set_af(utm_ctx *c, int32_t chunk, int mode, const void *af)
         TRY(ensure_var_count(c));
         u64 *d_keep = nullptr;
         HIP_TRY(hipMalloc(&d_keep, ch->w * 8));
-        HIP_TRY(hipMemcpy(d_keep, keep.data(), ch->w * 8, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, d_keep, keep.data(), ch->w * 8, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_mask_rows, dim3(4096), dim3(256), 0, c->stream, ch->cols, ch->wp, d_keep, ch->w, c->n_local);
         hipError_t e = hipStreamSynchronize(c->stream);
         (void)hipFree(d_keep);
@@ -578,18 +586,20 @@ static int build_af_tables(utm_ctx *c)
         Chunk &ch = c->chunks[k];
         const size_t n = ch.wp * 64;
         HIP_TRY(hipMalloc(&ch.af32, n * 4));
-        HIP_TRY(hipMemcpy(ch.af32, v32[k].data(), n * 4, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, ch.af32, v32[k].data(), n * 4, hipMemcpyHostToDevice));
         if (c->af_mode == UTM_AF_F32) {
             ch.af = ch.af32;
         } else {
             HIP_TRY(hipMalloc(&ch.af, n * 8));
-            HIP_TRY(hipMemset(ch.af, 0, n * 8));
-            HIP_TRY(hipMemcpy(ch.af, ch.h_af64.data(), ch.n_var * 8, hipMemcpyHostToDevice));
+            // (the context's stream is non-blocking: never mix in null-stream work, it would not be ordered with it)
+            HIP_TRY(hipMemsetAsync(ch.af, 0, n * 8, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(copy_sync(c, ch.af, ch.h_af64.data(), ch.n_var * 8, hipMemcpyHostToDevice));
         }
         seq.push_back(SeqChunk{ch.cols, ch.covered, ch.af, ch.wp, ch.w});
     }
     HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
-    HIP_TRY(hipMemcpy(c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
     // segment table + buffers of the chains' fast path
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     c->d_segs = nullptr;
@@ -601,7 +611,7 @@ static int build_af_tables(utm_ctx *c)
         const size_t n = segs.size();
         if (n * UTM_FAST_CAND * UTM_SEG_CAP * 8 <= (4ull << 30)) {  // keep the scratch within 4 GiB
             HIP_TRY(hipMalloc(&c->d_segs, n * sizeof(ChainSeg)));
-            HIP_TRY(hipMemcpy(c->d_segs, segs.data(), n * sizeof(ChainSeg), hipMemcpyHostToDevice));
+            HIP_TRY(copy_sync(c, c->d_segs, segs.data(), n * sizeof(ChainSeg), hipMemcpyHostToDevice));
             HIP_TRY(hipMalloc(&c->chain_fast.counts, n * UTM_FAST_CAND * 4));
             HIP_TRY(hipMalloc(&c->chain_fast.vals, n * UTM_FAST_CAND * UTM_SEG_CAP * 8));
             c->chain_fast.segs = c->d_segs;
@@ -621,7 +631,7 @@ static int ensure_xbuf(utm_ctx *c, int n_ranks)
     (void)hipFree(c->d_xbuf);
     c->d_xbuf = nullptr;
     HIP_TRY(hipMalloc(&c->d_xbuf, (size_t)n_ranks * slot * 8));
-    HIP_TRY(hipMemset(c->d_xbuf, 0, (size_t)n_ranks * slot * 8));
+    HIP_TRY(hipMemsetAsync(c->d_xbuf, 0, (size_t)n_ranks * slot * 8, c->stream));  // same stream as every later use
     c->xbuf_ranks = n_ranks;
     c->xbuf_slot_words = slot;
     return UTM_OK;
@@ -821,7 +831,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                 unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)af_target / std::max<u64>(1, tiles)));
                 unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
                 n_groups = (a_ub + group - 1) / group;
-                hipLaunchKernelGGL(k_score_afq, dim3((unsigned)(tiles * n_groups)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
+                hipLaunchKernelGGL(k_score_afq, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
                                    ch.af32, 150 - c->af_q, pending_of(c, ch, true), c->d_st, c->d_act,
                                    c->d_cnt, c->d_afsum, group, n_groups);
             } else {
@@ -841,7 +851,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                 u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
                 group = std::max<u64>(waves, (group + waves - 1) / waves * waves);
                 const unsigned n_groups = (unsigned)((a_ub + group - 1) / group);
-                const unsigned blocks = (unsigned)(tiles * n_groups);
+                const unsigned blocks = (unsigned)round_up(tiles * n_groups, 8);  // XCD-aware map: tile_of_block()
                 if (c->af_mode != UTM_AF_NONE) {
                     const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
                     const int eb = 150 - c->af_q;
@@ -1022,7 +1032,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         c->decr_entries_seen = c->h_st->decr_entries;
         c->decr_gathers_seen = c->h_st->decr_gathers;
         c->keep_valid = c->decr_enabled;  // a full pass mirrored the counts; a decremental one kept them current
-        if (rows > 0) HIP_TRY(hipMemcpy(&c->last_new, c->d_res_new + c->iter - 1, 8, hipMemcpyDeviceToHost));
+        if (rows > 0) HIP_TRY(copy_sync(c, &c->last_new, c->d_res_new + c->iter - 1, 8, hipMemcpyDeviceToHost));
         c->scored += passes;
         if (c->flags & UTM_FLAG_PROFILE_EVENTS) TRY(collect_event_times(c));
     }
@@ -1033,9 +1043,9 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     c->loop_ms = ms;
     const i64 rows = c->iter - iter0;
     if (rows > 0) {
-        HIP_TRY(hipMemcpy(idx_out, c->d_res_idx + iter0, rows * 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(new_out, c->d_res_new + iter0, rows * 8, hipMemcpyDeviceToHost));
-        if (score_out) HIP_TRY(hipMemcpy(score_out, c->d_res_score + iter0, rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(c, idx_out, c->d_res_idx + iter0, rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(c, new_out, c->d_res_new + iter0, rows * 8, hipMemcpyDeviceToHost));
+        if (score_out) HIP_TRY(copy_sync(c, score_out, c->d_res_score + iter0, rows * 8, hipMemcpyDeviceToHost));
     }
     *n_done = rows;
     return UTM_OK;
@@ -1072,8 +1082,8 @@ extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
     (void)hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream);
     (void)hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess && counts) e = hipMemcpy(counts, d_counts, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && scores) e = hipMemcpy(scores, d_scores, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && counts) e = copy_sync(c, counts, d_counts, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && scores) e = copy_sync(c, scores, d_scores, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
     (void)hipFree(d_counts);
     (void)hipFree(d_scores);
     if (e != hipSuccess) return fail(UTM_EHIP, "peek: %s", hipGetErrorString(e));
@@ -1214,9 +1224,9 @@ extern "C" int utm_apply_records(utm_ctx *c, const utm_record *recs, int32_t n_r
     int64_t i = -1, n = 0;
     double s = 0;
     if (c->iter > before) {
-        HIP_TRY(hipMemcpy(&i, c->d_res_idx + before, 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&n, c->d_res_new + before, 8, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&s, c->d_res_score + before, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(c, &i, c->d_res_idx + before, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(c, &n, c->d_res_new + before, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(c, &s, c->d_res_score + before, 8, hipMemcpyDeviceToHost));
     }
     if (idx) *idx = i;
     if (new_count) *new_count = n;
@@ -1287,10 +1297,10 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
         }
     }
     HIP_TRY(hipMalloc(&c->d_peer_first, (size_t)n_ranks * 4));
-    HIP_TRY(hipMemcpy(c->d_peer_first, firsts.data(), (size_t)n_ranks * 4, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, c->d_peer_first, firsts.data(), (size_t)n_ranks * 4, hipMemcpyHostToDevice));
     for (size_t k = 0; k < c->chunks.size(); ++k) {
         HIP_TRY(hipMalloc(&c->chunks[k].d_peer_cols, (size_t)n_ranks * sizeof(u64 *)));
-        HIP_TRY(hipMemcpy(c->chunks[k].d_peer_cols, table[k].data(), (size_t)n_ranks * sizeof(u64 *), hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, c->chunks[k].d_peer_cols, table[k].data(), (size_t)n_ranks * sizeof(u64 *), hipMemcpyHostToDevice));
     }
     c->p2p = true;
     c->prepared = false;  // exchange slots shrink to records
@@ -1330,10 +1340,10 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
         int ok = utm_p2p_export(c, mine.data()) == UTM_OK;
         char *d_all = nullptr;
         HIP_TRY(hipMalloc(&d_all, blob * n_ranks));
-        HIP_TRY(hipMemcpy(d_all + blob * rank, mine.data(), blob, hipMemcpyHostToDevice));
+        HIP_TRY(copy_sync(c, d_all + blob * rank, mine.data(), blob, hipMemcpyHostToDevice));
         NCCL_TRY(g_rccl.AllGather(d_all + blob * rank, d_all, blob, ncclChar, c->comm, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(hipMemcpy(all.data(), d_all, blob * n_ranks, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(c, all.data(), d_all, blob * n_ranks, hipMemcpyDeviceToHost));
         (void)hipFree(d_all);
         if (ok) ok = utm_p2p_import(c, rank, n_ranks, all.data()) == UTM_OK;
         double flag = ok ? 1.0 : 0.0, neg = -flag;   // min over ranks = -max(-flag)
