@@ -178,8 +178,8 @@ __device__ __forceinline__ bool tile_of_block(u64 wp, unsigned tile_words, unsig
 // + one ds_read_b128 + 4x(v_and, v_bcnt) per step, a wave reduction and ONE 64-bit atomic per
 // (sample, tile).  Integer adds: exact and order independent.
 // ------------------------------------------------------------------------------------------------
-template <int STEPS, bool NT, int WAVES, bool PIPE>
-__global__ __launch_bounds__(WAVES * 64) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+template <int STEPS, bool NT>
+__global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, unsigned group_size, unsigned n_groups)
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_int(const u64 *__restrict_
     v4u *cv = reinterpret_cast<v4u *>(covered + w0);
     const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
     const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
-    for (int i = threadIdx.x; i < nsteps * 64; i += WAVES * 64) {
+    for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
         v4u c = cv[i];
         if (wc) {
             c |= wc[i];
@@ -212,49 +212,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_int(const u64 *__restrict_
     const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int U = STEPS < 8 ? STEPS : 8;  // loads in flight per wave: U KiB
-    for (unsigned i = lo + wave; i < hi; i += WAVES) {
+    for (unsigned i = lo + wave; i < hi; i += 4) {
         const unsigned s = act[i];
         const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
         unsigned acc = 0;
         if (nsteps == STEPS) {
-            if constexpr (PIPE && STEPS >= 2 * U) {
-                // two batches of U KiB in flight: the next batch is issued before the current one is consumed
-                v4u xa[U], xb[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) xa[u] = NT ? __builtin_nontemporal_load(p + u * 64) : p[u * 64];
 #pragma unroll 1
-                for (int j0 = 0; j0 < STEPS; j0 += 2 * U) {
+            for (int j0 = 0; j0 < STEPS; j0 += U) {
+                v4u x[U];
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        xb[u] = NT ? __builtin_nontemporal_load(p + (j0 + U + u) * 64) : p[(j0 + U + u) * 64];
+                for (int u = 0; u < U; ++u)
+                    x[u] = NT ? __builtin_nontemporal_load(p + (j0 + u) * 64) : p[(j0 + u) * 64];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const v4u b = xa[u] & live[(j0 + u) * 64 + lane];
-                        acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
-                    }
-                    if (j0 + 2 * U < STEPS) {
-#pragma unroll
-                        for (int u = 0; u < U; ++u)
-                            xa[u] = NT ? __builtin_nontemporal_load(p + (j0 + 2 * U + u) * 64) : p[(j0 + 2 * U + u) * 64];
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const v4u b = xb[u] & live[(j0 + U + u) * 64 + lane];
-                        acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
-                    }
-                }
-            } else {
-#pragma unroll 1
-                for (int j0 = 0; j0 < STEPS; j0 += U) {
-                    v4u x[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u)
-                        x[u] = NT ? __builtin_nontemporal_load(p + (j0 + u) * 64) : p[(j0 + u) * 64];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const v4u b = x[u] & live[(j0 + u) * 64 + lane];
-                        acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
-                    }
+                for (int u = 0; u < U; ++u) {
+                    const v4u b = x[u] & live[(j0 + u) * 64 + lane];
+                    acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
                 }
             }
         } else {

@@ -752,23 +752,14 @@ static int tune_env(const char *name, int dflt)
 }
 
 template <int STEPS>
-static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups, bool nt, int waves)
+static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups, bool nt)
 {
-#define UTM_LAUNCH_INT(NT, W, P)                                                                                           \
-    hipLaunchKernelGGL((k_score_int<STEPS, NT, W, P>), dim3(blocks), dim3(W * 64), 0, c->stream, ch.cols, ch.covered, ch.wp,   \
-                       pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups)
-    static const int pipe = tune_env("UTM_INT_PIPE", 0);
-    if (waves == 8) {
-        if (nt) UTM_LAUNCH_INT(true, 8, false);
-        else UTM_LAUNCH_INT(false, 8, false);
-    } else if (pipe) {
-        if (nt) UTM_LAUNCH_INT(true, 4, true);
-        else UTM_LAUNCH_INT(false, 4, true);
-    } else {
-        if (nt) UTM_LAUNCH_INT(true, 4, false);
-        else UTM_LAUNCH_INT(false, 4, false);
-    }
-#undef UTM_LAUNCH_INT
+    if (nt)
+        hipLaunchKernelGGL((k_score_int<STEPS, true>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
+                           pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
+    else
+        hipLaunchKernelGGL((k_score_int<STEPS, false>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
+                           pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
 }
 
 // Enqueue the scoring of one iteration for every chunk (and the pending covered update).
@@ -846,10 +837,8 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                 }
                 if (c->af_mode == UTM_AF_NONE && (force_steps == 32 || force_steps == 8 || force_steps == 2)) steps = force_steps;
                 const u64 tiles = (steps_total + steps - 1) / steps;
-                static const int int_waves = tune_env("UTM_INT_WAVES", 4) == 8 ? 8 : 4;
-                const int waves = c->af_mode == UTM_AF_NONE ? int_waves : 4;
                 u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
-                group = std::max<u64>(waves, (group + waves - 1) / waves * waves);
+                group = std::max<u64>(4, (group + 3) / 4 * 4);
                 const unsigned n_groups = (unsigned)((a_ub + group - 1) / group);
                 const unsigned blocks = (unsigned)round_up(tiles * n_groups, 8);  // XCD-aware map: tile_of_block()
                 if (c->af_mode != UTM_AF_NONE) {
@@ -863,9 +852,9 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
                     else if (steps == 8) UTM_LAUNCH_AFG(8, 1024);
                     else UTM_LAUNCH_AFG(2, 1024);
 #undef UTM_LAUNCH_AFG
-                } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt, waves);
-                else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt, waves);
-                else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt, waves);
+                } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+                else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+                else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
             }
             ev_end();
             c->score_launches += 1;
