@@ -491,3 +491,43 @@ def test_full_size_select_all_invariants(dev, decremental):
     rows = test_full_size_select_all_invariants.rows
     if len(rows) == 2:
         assert rows[False] == rows[True]
+
+
+def test_randomised_configurations_against_the_oracle(dev):
+    """Seeded sweep over shapes, chunkings, sample states, weights, AF modes and the decremental switch:
+    every configuration must give the oracle's indices, counts and float64 scores."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("UTM_FUZZ_SEED", "2026")))
+    for trial in range(int(os.environ.get("UTM_FUZZ_TRIALS", "70"))):
+        n_var = int(rng.choice([1, 5, 63, 64, 65, 127, 500, 1500, 4000, 9000]))
+        n_samp = int(rng.choice([1, 2, 3, 7, 33, 64, 65, 130, 257]))
+        density = float(rng.choice([0.01, 0.05, 0.3, 0.7]))
+        dense = rng.random((n_var, n_samp)) < density
+        if rng.random() < 0.7:
+            dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True   # mostly informative rows, sometimes not
+        if rng.random() < 0.3 and n_samp > 3:
+            dense[:, 1] = dense[:, 0]                                           # exact ties
+        state = np.ones(n_samp, np.uint8)
+        if n_samp > 4:
+            state[rng.choice(n_samp, rng.integers(0, 3), replace=False)] = 2
+            state[rng.choice(n_samp, rng.integers(0, 2), replace=False)] = 0
+        weights = None
+        if rng.random() < 0.4:
+            weights = rng.choice([-2.0, 0.0, 0.5, 1.0, 1.0, 3.0], n_samp)
+        af = None
+        mode = rng.choice(["none", "none", "f32", "f64"])
+        if mode != "none":
+            af = rng.random(n_var) * rng.choice([1.0, 1e-3])
+            af[rng.random(n_var) < 0.05] = 0.0
+            af = af.astype(np.float32) if mode == "f32" else af
+        chunks = None
+        if n_var > 200 and rng.random() < 0.5:
+            cuts = sorted(set(int(x) for x in rng.integers(1, n_var, rng.integers(1, 4))))
+            chunks = [0] + cuts + [n_var]
+        k = int(rng.integers(1, n_samp + 1))
+        decr = 1.0 if rng.random() < 0.4 else None
+        try:
+            check_run(dev, dense, state=state, weights=weights, af=af, k=k, chunks=chunks, decremental=decr)
+        except AssertionError as e:
+            raise AssertionError(f"trial {trial}: n_var={n_var} n_samp={n_samp} density={density} mode={mode} "
+                                 f"chunks={chunks} k={k} decr={decr} weights={'yes' if weights is not None else 'no'}") from e
