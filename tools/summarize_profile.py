@@ -11,19 +11,25 @@ so the read side is doubled; WRITE_SIZE is taken as is.  Counters are collected 
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 
+def newest(pattern):
+    """Several runs may have written into one directory (PID-prefixed files): take the latest."""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
+
 def pmc_rows(d, prefix):
-    f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
+    f = newest(f"{d}/**/*_counter_collection.csv")
     return [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(tuple(prefix.split(",")))]
 
 
 def main():
     tag, kt_dir, fetch_dir, write_dir, algo_note = sys.argv[1:6]
     prefix = sys.argv[6] if len(sys.argv) > 6 else "void k_score_int"
-    stats = glob.glob(f"{kt_dir}/**/*_kernel_stats.csv", recursive=True)[0]
+    stats = newest(f"{kt_dir}/**/*_kernel_stats.csv")
     shutil.copyfile(stats, f"profiles/{tag}_kernel_stats.csv")
     fr, wr = pmc_rows(fetch_dir, prefix), pmc_rows(write_dir, prefix)
     n = min(len(fr), len(wr))
