@@ -340,16 +340,17 @@ __device__ __forceinline__ u64 af_fixed(unsigned f, int e_base)
     return (u64)((f & 0x7FFFFFu) | 0x800000u) << ((f >> 23) - e_base);
 }
 
+// CAP = queue depth per LANE: every lane keeps its own little queue (slot-major in LDS, so a wave's
+// pushes are conflict free) -- no cross-lane prefix sum is needed to place an entry.
 template <int STEPS, int CAP>
 __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
-                                                   const unsigned *__restrict__ afbits, int e_base,
-                                                   const Pending pend,
+                                                   const unsigned *__restrict__ afbits, int e_base, const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
                                                    unsigned n_groups)
 {
     __shared__ v4u live[STEPS * 64];
-    __shared__ unsigned queue[4][CAP];
+    __shared__ unsigned queue[4][CAP][64];
     if (st->done) return;
     unsigned tile, grp;
     if (!tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp)) return;
@@ -374,18 +375,21 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
     const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int U = STEPS < 8 ? STEPS : 8;
-    unsigned *q = queue[wave];
+    unsigned(*q)[64] = queue[wave];
     const unsigned *af_tile = afbits + w0 * 64;  // AF of the tile's first variant
     for (unsigned i = lo + wave; i < hi; i += 4) {
         const unsigned s = act[i];
         const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
-        unsigned acc = 0, qn = 0;  // qn is wave uniform
+        unsigned acc = 0, qc = 0;  // qc: entries in this lane's queue
         u64 sum = 0;
         auto drain = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            for (unsigned e = lane; e < qn; e += 64) sum += af_fixed(af_tile[q[e]], e_base);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            qn = 0;
+            for (unsigned j = 0; __ballot(j < qc) != 0; j += 2) {  // two independent gathers per round
+                const unsigned f0 = j < qc ? af_tile[q[j][lane]] : 0u;
+                const unsigned f1 = j + 1 < qc ? af_tile[q[j + 1][lane]] : 0u;
+                if (j < qc) sum += af_fixed(f0, e_base);
+                if (j + 1 < qc) sum += af_fixed(f1, e_base);
+            }
+            qc = 0;
         };
         for (int j0 = 0; j0 < nsteps; j0 += U) {
             v4u b[U];
@@ -400,26 +404,23 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
             }
             acc += nb;
             if (__ballot(nb != 0) == 0) continue;  // nothing survived in these 8 KiB
-            const unsigned incl = wave_scan_incl_u32(nb);
-            const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-            if (qn + total > CAP) drain();
+            if (__ballot(qc + nb > CAP) != 0) drain();
             const unsigned base = (unsigned)(j0 * UTM_STEP_WORDS + 2 * lane) * 64;  // variant offset inside the tile
-            if (total <= CAP) {
-                unsigned pos = qn + incl - nb;
+            if (__ballot(nb > CAP) == 0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
+                    if (__ballot((b[u].x | b[u].y | b[u].z | b[u].w) != 0) == 0) continue;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         unsigned bits = b[u][d];
                         const unsigned v0 = base + u * (UTM_STEP_WORDS * 64) + d * 32;
                         while (bits) {
-                            q[pos++] = v0 + __builtin_ctz(bits);
+                            q[qc++][lane] = v0 + __builtin_ctz(bits);
                             bits &= bits - 1;
                         }
                     }
                 }
-                qn += total;
-            } else {  // dense data: more bits in one batch than the queue holds -- gather them directly
+            } else {  // dense data: some lane has more bits in one batch than its queue holds -- gather directly
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
 #pragma unroll
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
                 }
             }
         }
-        if (qn) drain();
+        if (__ballot(qc != 0) != 0) drain();
         const unsigned n = wave_sum_u32(acc);
         if (n) {  // wave uniform
             const i64 total = wave_sum_u63(sum);

@@ -847,10 +847,10 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
 #define UTM_LAUNCH_AFG(S, Q)                                                                                              \
     hipLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb,   \
                        pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups)
-                    if (steps == 32) UTM_LAUNCH_AFG(32, 512);
-                    else if (steps == 16) UTM_LAUNCH_AFG(16, 1024);
-                    else if (steps == 8) UTM_LAUNCH_AFG(8, 1024);
-                    else UTM_LAUNCH_AFG(2, 1024);
+                    if (steps == 32) UTM_LAUNCH_AFG(32, 8);       // queue depth per lane
+                    else if (steps == 16) UTM_LAUNCH_AFG(16, 16);
+                    else if (steps == 8) UTM_LAUNCH_AFG(8, 16);
+                    else UTM_LAUNCH_AFG(2, 16);
 #undef UTM_LAUNCH_AFG
                 } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
                 else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
