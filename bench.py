@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--no-roofline-pass", action="store_true")
     p.add_argument("--decremental", action="store_true",
                    help="SURVEY 8f-4 shortcut (exact, reads far fewer bytes): reported separately, never the default")
+    p.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip rank 0's single-GPU re-run and comparison")
     p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the exchange path)")
     return p.parse_args()
 
@@ -178,6 +179,25 @@ def main():
                 roofline["traffic"] = json.load(fh)["hbm_bytes_per_launch_mean"]
             roofline["traffic_source"] = os.path.relpath(rec, ROOT) + " (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
 
+    # N > 1: rank 0 re-runs the whole problem alone (untimed, own context) and compares the rows -- evidence
+    # from this very run that the sharded exchange decides exactly like a single GPU
+    sharded_check = None
+    if (world > 1 or args.force_comm) and rank == 0 and not args.no_sharded_check:
+        with device.DeviceMatrix(n_total, device=local_rank) as solo:
+            v0 = 0
+            while v0 < args.n_var:
+                nv = min(chunk_vars, args.n_var - v0)
+                c = solo.add_chunk(nv)
+                solo.synth_fill(c, seed=args.seed, first_var_global=v0)
+                if args.af:
+                    _, af = device.synth_host(args.seed, nv, n_total, first_var_global=v0, want_cols=False)
+                    solo.set_af(c, af if args.af_dtype == "f32" else af.astype(np.float64) / 3.0)
+                v0 += nv
+            s_idx, s_new, s_score = solo.run(k_sel)
+        sharded_check = bool(len(s_idx) == len(idx) and (s_idx == idx).all() and (s_new == new).all())
+        if not sharded_check:
+            sys.stderr.write("bench.py: SHARDED RESULT DIFFERS FROM THE SINGLE-GPU RESULT\n")
+
     cpu = bitset = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, bitset = cpu_baseline(args, device)
@@ -209,6 +229,7 @@ def main():
         "brute_force_equivalent_gbps": st["brute_force_bytes"] * world * args.steps / elapsed / 1e9,
         "hbm_gbps_whole_loop": whole_loop_gbps, "hbm_frac_whole_loop": whole_loop_gbps / (HBM_PEAK_GBPS * world),
         "device_loop_ms_per_step": loop_ms / max(1, args.steps),
+        "sharded_rows_match_single_gpu": sharded_check,
         "roofline": roofline, "cpu_baseline": cpu, "cpu_bitset_baseline": bitset,
     }
     print(json.dumps(line))
