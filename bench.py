@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--decremental", action="store_true",
                    help="SURVEY 8f-4 shortcut (exact, reads far fewer bytes): reported separately, never the default")
     p.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip rank 0's single-GPU re-run and comparison")
+    p.add_argument("--exchange", choices=["auto", "rccl"], default="auto",
+                   help="N > 1: auto = device mailboxes over hipIpc mappings when every rank can, else RCCL; rccl = force RCCL")
     p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the exchange path)")
     return p.parse_args()
 
@@ -125,9 +127,33 @@ def main():
             m.set_af(c, af if args.af_dtype == "f32" else af.astype(np.float64) / 3.0)
         v0 += nv
     t_gen = time.perf_counter() - t_gen
-    if world > 1 or args.force_comm:
+    exchange = "none"
+    id_path = None
+    transport = None
+    if world > 1:
+        # start-up over a local TCP socket (port published in the launch's rendezvous file).  Default exchange:
+        # every rank maps every other rank's columns and record mailboxes (hipIpc), the mappings are self-tested,
+        # and the loop then runs without any host or collective in it.  If that is not possible on every rank
+        # (or with --exchange rccl) the RCCL communicator carries the per-iteration exchange instead.
+        from utmos_amd.sharded import bootstrap, enable_p2p
+        transport, uid = bootstrap(rank, world, device.DeviceMatrix.comm_unique_id)
+        if args.exchange != "rccl":
+            enable_p2p(m, transport)
+        if not m.fused_mailboxes:
+            m.comm_init(rank, world, uid)
+        exchange = "device mailboxes + in-place column reads over hipIpc mappings (xGMI)" if m.fused_mailboxes else (
+            "ncclAllGather of records, winner column read over hipIpc" if m.p2p else "ncclAllGather of records + columns")
+    elif args.force_comm:
         uid, id_path = rendezvous_id(rank, world, device.DeviceMatrix.comm_unique_id)
         m.comm_init(rank, world, uid)
+        exchange = "ncclAllGather (single rank)"
+
+    def sync_max(value):
+        """Barrier + maximum over the ranks (host side: the ranks' loops are already drained)."""
+        if transport is None:
+            return value
+        return max(r[0] for r in transport.allgather((float(value), 0, 0)))
+
     k_sel = n_total if args.select < 0 else min(args.select, n_total)
     if args.decremental:
         m.set_decremental(True)
@@ -138,7 +164,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    m.allreduce_max(0.0)  # barrier (run() returns only after its stream has drained)
+    sync_max(0.0)  # barrier (run() returns only after its stream has drained)
     t0 = time.perf_counter()
     iters = 0
     loop_ms = 0.0
@@ -147,7 +173,7 @@ def main():
         iters += len(idx)
         loop_ms += m.stats()["loop_ms"]
     elapsed = time.perf_counter() - t0
-    elapsed = m.allreduce_max(elapsed)
+    elapsed = sync_max(elapsed)
     st = m.stats()
     algo_bytes_step = st["algo_bytes"]          # since the last reset = one step, this rank's shard
     tot_captured = st["tot_captured"]
@@ -202,14 +228,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, bitset = cpu_baseline(args, device)
 
-    if (world > 1 or args.force_comm) and rank == 0:
+    if id_path and rank == 0:
         try:
             os.remove(id_path)
         except OSError:
             pass
     if rank != 0:
+        sync_max(0.0)      # nobody unmaps its columns while a peer may still be finishing
+        if transport is not None:
+            transport.close()
         m.close()
         return
+    sync_max(0.0)
     value = iters / elapsed
     whole_loop_gbps = algo_bytes_step * world * args.steps / elapsed / 1e9   # shards are equal-sized to within one sample
     line = {
@@ -221,7 +251,7 @@ def main():
                                f"{'all' if args.select < 0 else k_sel}{(', --af ' + args.af_dtype) if args.af else ''}",
                    "n_var": args.n_var, "n_samp": n_total, "iterations_per_step": iters // max(1, args.steps),
                    "tot_captured": tot_captured, "chunks": st["n_chunks"], "seed": args.seed,
-                   "sharding": f"sample axis over {world} GPU(s), one ncclAllGather per iteration" if world > 1 else "none",
+                   "sharding": f"sample axis over {world} GPU(s); per-iteration exchange: {exchange}" if world > 1 else "none",
                    "generator_s": round(t_gen, 3), "af_verified_parallel": st["af_fixed_point"] if args.af else None},
         "scoring": "decremental after the first passes (bytes = what this variant actually reads; NOT the brute-force "
                    "roofline metric)" if args.decremental else "brute force: every selectable column re-read every iteration",
@@ -233,6 +263,8 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "cpu_bitset_baseline": bitset,
     }
     print(json.dumps(line))
+    if transport is not None:
+        transport.close()
     m.close()
 
 

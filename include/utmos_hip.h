@@ -163,13 +163,21 @@ int utm_apply_records(utm_ctx *ctx, const utm_record *recs, int32_t n_ranks, con
 int utm_p2p_blob_bytes(utm_ctx *ctx, uint64_t *n_bytes);
 int utm_p2p_export(utm_ctx *ctx, void *blob);
 int utm_p2p_import(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *blobs);
+/* Record mailboxes: with the mappings in place the shards can also exchange their per-iteration records on
+ * the device (remote stores into each other's uncached mailbox slots, bounded polling) -- no collective and no
+ * host in the loop.  utm_p2p_selftest is collective (every shard calls it): *ok = 1 when this shard received
+ * every peer's test record.  If ALL shards report 1, call utm_p2p_use_mailboxes(ctx, 1) on every shard; utm_run
+ * is then collective over the shards exactly like after utm_comm_init. */
+int utm_p2p_selftest(utm_ctx *ctx, int32_t *ok);
+int utm_p2p_use_mailboxes(utm_ctx *ctx, int32_t on);
 
 /* ---- RCCL (one process per GPU; ids are exchanged by the caller) ------------------------------ */
 #define UTM_UNIQUE_ID_BYTES 128
 int utm_comm_get_unique_id(void *id);
-/* After this, utm_step / utm_run are collective: one ncclAllGather of the shards' records per iteration;
- * the winner's column is read over P2P mappings (set up here), or rides in the same all-gather when the
- * mappings cannot be made on every rank. */
+/* After this, utm_step / utm_run are collective.  utm_comm_init also sets up the P2P mappings and the record
+ * mailboxes and self-tests them; per iteration the shards then exchange 64-byte records through the mailboxes
+ * (or one ncclAllGather when the self-test fails anywhere) and read the winner's column in place (or receive
+ * it in the same all-gather when the mappings cannot be made on every rank). */
 int utm_comm_init(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *id);
 int utm_comm_allreduce_max(utm_ctx *ctx, double *value); /* in place; also a barrier */
 

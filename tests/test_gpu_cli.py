@@ -135,3 +135,29 @@ def test_cli_two_processes_sharded_over_samples(name, tmp_path):
         p.join(timeout=60)
     assert res == {0: "ok", 1: "ok"}
     assert open(out).read() == ou.golden_text(CASES[name])
+
+
+def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N > 1 (one process per rank, RANK / WORLD_SIZE / LOCAL_RANK /
+    MASTER_* in the environment) -- here three ranks that all sit on the box's single GPU, small workload.
+    Rank 0 prints the one JSON line; the sharded rows equal its own single-GPU re-run."""
+    import json
+    import subprocess
+    import sys
+    port = 41500 + os.getpid() % 2000
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TMPDIR=str(tmp_path))
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ou.ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
+             "--n-var", "400000", "--n-samp", "301", "--no-cpu-baseline"],
+            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0, 0], [o[1][-400:] for o in outs]
+    assert outs[1][0].strip() == "" and outs[2][0].strip() == ""          # only rank 0 reports
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["sharded_rows_match_single_gpu"] is True
+    assert "mailboxes" in line["config"]["sharding"]
+    assert line["config"]["iterations_per_step"] == 301

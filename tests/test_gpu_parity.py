@@ -361,6 +361,60 @@ def test_p2p_winner_columns_read_in_place_across_processes(dev):
     assert all(r[1] for r in res) and res[0][2] == res[1][2] == res[2][2] > 30, res
 
 
+def _gpu_fused_worker(rank, world, port, q):
+    from utmos_amd.sharded import SocketTransport, enable_p2p, shard_bounds
+    transport = SocketTransport(rank, world, port=port)
+    try:
+        from utmos_amd import device
+        n_var, n_samp = 64 * 128 * 7 + 5, 90
+        cols, af = device.synth_host(8, n_var, n_samp)
+        state = np.ones(n_samp, np.uint8)
+        state[[3, 60]] = 2
+        w = np.where(np.arange(n_samp) % 5 == 0, 2.0, 1.0)
+        first, n_local = shard_bounds(n_samp, rank, world)
+        out = {}
+        with device.DeviceMatrix(n_samp, device=0, first_sample=first, n_local=n_local) as m:
+            c = m.add_chunk(n_var)
+            m.synth_fill(c, seed=8)
+            enable_p2p(m, transport)
+            fused = m.fused
+            for mode in ("int", "af32", "af64", "decr"):
+                m.set_af(c, None if mode in ("int", "decr") else (af if mode == "af32" else af.astype(np.float64) / 3.0))
+                m.set_decremental(mode == "decr", 1.0)
+                m.set_state(state)
+                m.set_weights(w)
+                idx, new, score = m.run(n_samp)            # collective: every shard gets every row
+                out[mode] = (idx.tolist(), new.tolist(), score.tolist())
+            transport.allgather((0.0, 0, 0))               # nobody unmaps while a peer may still read
+        ok = fused
+        for mode, got in out.items():
+            a = None if mode in ("int", "decr") else (af if mode == "af32" else af.astype(np.float64) / 3.0)
+            exp = ou.c_greedy(cols, n_var, state, w, af=a)
+            ok = ok and got[0] == exp[0].tolist() and got[1] == exp[1].tolist() and got[2] == exp[2].tolist()
+        q.put((rank, ok, len(out["int"][0]), f"fused={fused}"))
+    except BaseException as e:  # noqa: BLE001
+        q.put((rank, False, 0, repr(e)))
+    finally:
+        transport.close()
+
+
+def test_fused_device_side_exchange_three_processes(dev):
+    """The production multi-shard loop without RCCL in it: records through hipIpc-mapped mailboxes, winner
+    columns read in place, utm_run collective over three processes (sharing the box's one GPU)."""
+    import multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gpu_fused_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res) and res[0][2] == res[1][2] == res[2][2] > 40, res
+
+
 def _gpu_shard_worker(rank, world, port, q):
     # no torch in a process that runs libutmos_hip.so: its wheel carries another HIP runtime
     from utmos_amd.sharded import SocketTransport

@@ -35,6 +35,9 @@ struct IterState {
     int cand_overflow;  // more candidates than UTM_MAX_CAND: every sample is re-scored sequentially
     int all_exact;      // every selectable sample's estimate is exact; scores only shrink, so it stays that way
     // decremental scoring: work actually done (for the byte accounting)
+    u64 xseq;           // mailbox exchanges completed (identical on every shard)
+    int xerror;         // a peer's record did not arrive in time
+    int pad_;
     u64 decr_entries;   // sum over decremental iterations of the newly-covered word count
     u64 decr_gathers;   // ... of (selectable samples x newly-covered words)
 };
@@ -52,6 +55,16 @@ struct Rec {  // == utm_record
     i64 idx;
     i64 new_count;
     i64 pad[5];
+};
+
+// Record mailbox for the device-side exchange between shards: every shard owns 2 x n_ranks slots in uncached
+// device memory that all peers map (hipIpc); slot [seq & 1][r] receives rank r's record of exchange `seq`.
+struct Mailbox {
+    double score;
+    i64 idx;
+    i64 new_count;
+    u64 seq;   // written last (release): the slot is complete when it equals the expected sequence number
+    u64 pad[4];
 };
 
 struct SeqChunk {
@@ -83,6 +96,8 @@ struct PickArgs {
     int n_chunks;
     double *fscore;  // sequential AF scores, or nullptr
     double af_scale; // 2^-q
+    Mailbox *mbox;             // this shard's mailbox slots [2][n_ranks], or nullptr
+    Mailbox *const *peer_mbox; // every shard's mailbox base, as mapped here (index = rank)
     CandBuf *cand;   // verified-parallel AF: candidate list, else nullptr
     int af_is_f64;   // the estimate sums float32-rounded values of float64 AFs
     Rec *recs;       // exchange slot headers: recs[r] at xbuf + r*slot_words
@@ -899,10 +914,13 @@ __device__ void decide(const PickArgs &a)
     if (st->tot >= a.n_var_total) st->done = 1;  // "Ran out of new variants" (select.py:110-112)
 }
 
-template <bool DECIDE>
+// MODE 0: single shard -- pick and decide.  1: write this shard's record into its exchange slot.
+// 2: as 1, and post the record into every shard's mailbox (device-side exchange over P2P mappings).
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
 {
     __shared__ Cand wbest[16];
+    __shared__ Rec srec;
     IterState *st = a.st;
     if (st->done) return;
     const unsigned n_active = st->n_active;
@@ -955,6 +973,11 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
         rc->idx = n_active ? best.gidx : -1;
         rc->new_count = n_active ? best.cnt : 0;
         st->best_pos = best.pos;
+        if (MODE == 2) {
+            srec.score = rc->score;
+            srec.idx = rc->idx;
+            srec.new_count = rc->new_count;
+        }
         if (a.list_n) {
             u64 n_l = 0;
             for (int c = 0; c < a.n_chunks; ++c) {
@@ -964,7 +987,21 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
             st->decr_entries += n_l;
             st->decr_gathers += n_l * n_active;
         }
-        if (DECIDE) decide(a);
+        if (MODE == 0) decide(a);
+    }
+    if (MODE == 2) {
+        __syncthreads();
+        if ((int)threadIdx.x < a.n_ranks) {
+            // one lane per destination shard; payload first, sequence number last (release, system scope)
+            const u64 seq = st->xseq + 1;
+            Mailbox *dst = a.peer_mbox[threadIdx.x] + (seq & 1) * a.n_ranks + a.rank;
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->score), __builtin_bit_cast(u64, srec.score), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->idx), (u64)srec.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->new_count), (u64)srec.new_count, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -972,6 +1009,67 @@ __global__ void k_decide(PickArgs a)
 {
     if (a.st->done) return;
     if (threadIdx.x == 0) decide(a);
+}
+
+// Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
+// landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
+#define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
+__device__ __forceinline__ bool mbox_wait(const Mailbox *slot, u64 expected, Rec *out)
+{
+    for (unsigned spin = 0; spin < UTM_MBOX_SPINS; ++spin) {
+        if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == expected) {
+            out->score = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&slot->score), __ATOMIC_RELAXED,
+                                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+            out->idx = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            out->new_count = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->new_count), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_SYSTEM);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void k_wait_decide(PickArgs a)
+{
+    __shared__ int late;
+    IterState *st = a.st;
+    if (st->done) return;
+    if (threadIdx.x == 0) late = 0;
+    __syncthreads();
+    const u64 expected = st->xseq + 1;
+    if ((int)threadIdx.x < a.n_ranks) {
+        const Mailbox *slot = a.mbox + (expected & 1) * a.n_ranks + threadIdx.x;
+        if (!mbox_wait(slot, expected, rec_of(a, threadIdx.x))) late = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (late) {
+            st->xerror = 1;  // a shard went away: end the loop, the host reports it
+            st->done = 1;
+            return;
+        }
+        st->xseq = expected;
+        decide(a);
+    }
+}
+
+// Mailbox self-test (utm_p2p_selftest): one full post + wait round with a recognisable payload.
+__global__ __launch_bounds__(64) void k_mbox_ping(Mailbox *mbox, Mailbox *const *peer_mbox, int rank, int n_ranks, u64 seq, int *ok)
+{
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < n_ranks) {
+        Mailbox *dst = peer_mbox[threadIdx.x] + (seq & 1) * n_ranks + rank;
+        __hip_atomic_store(reinterpret_cast<u64 *>(&dst->idx), (u64)(1000 * seq + rank), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        Rec got;
+        const Mailbox *slot = mbox + (seq & 1) * n_ranks + threadIdx.x;
+        if (!mbox_wait(slot, seq, &got) || got.idx != (i64)(1000 * seq + threadIdx.x)) bad = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && bad) *ok = 0;
 }
 
 // Exchange payload: this shard's best column (all chunks back to back) behind its record.

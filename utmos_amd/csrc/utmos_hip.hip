@@ -171,6 +171,12 @@ struct utm_ctx {
     // P2P: every rank maps every other rank's columns (hipIpc); the winner's column is then read in place
     bool p2p = false;
     unsigned *d_peer_first = nullptr;  // [n_ranks]
+    // record mailboxes (device-side exchange without a collective)
+    Mailbox *d_mbox = nullptr;           // local slots [2][UTM_MAX_RANKS], uncached device memory, exported to the peers
+    Mailbox **d_peer_mbox = nullptr;     // device array [n_ranks] of mapped mailbox bases
+    std::vector<void *> mbox_opened;
+    bool mbox_ok = false;                // every shard passed the mailbox self-test: utm_run exchanges through them
+    u64 xseq_host = 0;                   // exchanges completed so far (self-test rounds included)
 
     // stats
     i64 score_launches = 0;
@@ -253,6 +259,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     p2p_close(c);
+    (void)hipFree(c->d_mbox);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto &ch : c->chunks) {
         (void)hipFree(ch.cols);
@@ -642,7 +649,7 @@ extern "C" int utm_reset(utm_ctx *c)
     CTX(c);
     if (c->chunks.empty()) return fail(UTM_ESTATE, "no chunks");
     TRY(build_af_tables(c));
-    TRY(ensure_xbuf(c, c->xbuf_ranks));
+    TRY(ensure_xbuf(c, std::max(c->xbuf_ranks, c->n_ranks)));
     // local state + active list
     std::vector<unsigned> act;
     i64 active_total = 0;
@@ -667,6 +674,7 @@ extern "C" int utm_reset(utm_ctx *c)
     st.n_active = (unsigned)act.size();
     st.n_active_total = active_total;
     st.prev_local = -1;
+    st.xseq = c->xseq_host;  // the exchange sequence keeps counting across resets (every shard resets alike)
     HIP_TRY(hipMemcpyAsync(c->d_st, &st, sizeof st, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->decr_enabled) {
@@ -728,6 +736,8 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     a.fscore = c->af_mode != UTM_AF_NONE ? c->d_fscore : nullptr;  // sequential scores (fallback / overflow)
     a.af_scale = ldexp(1.0, -c->af_q);
     // float32 AF sums only shrink: once every estimate was exact (< 2^53 units) the plain exact pick suffices
+    a.mbox = c->d_mbox;
+    a.peer_mbox = c->d_peer_mbox;
     a.cand = (c->af_mode != UTM_AF_NONE && c->af_fixed && !c->af_all_exact) ? c->d_cand : nullptr;
     a.af_is_f64 = c->af_mode == UTM_AF_F64;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
@@ -926,19 +936,25 @@ static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
 {
     PickArgs a = pick_args(c, decr);
     enqueue_candidates(c, a);
-    if (!c->comm) {
-        hipLaunchKernelGGL(k_pick<true>, dim3(1), dim3(1024), 0, c->stream, a);
-    } else {
-        hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(1024), 0, c->stream, a);
+    if (c->n_ranks > 1 && c->mbox_ok) {
+        // device-side exchange: post this shard's record into every shard's mailbox, wait for theirs, decide
+        hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, c->stream, a);
+        hipLaunchKernelGGL(k_wait_decide, dim3(1), dim3(64), 0, c->stream, a);
+    } else if (c->comm) {
+        hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, c->stream, a);
         u64 *slot = c->d_xbuf + (u64)c->rank * c->xbuf_slot_words;
         if (!c->p2p)
             for (auto &ch : c->chunks)
                 hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
-                               slot + UTM_HDR_WORDS + ch.off, ch.cols, ch.wp, c->d_st, c->d_act);
+                                   slot + UTM_HDR_WORDS + ch.off, ch.cols, ch.wp, c->d_st, c->d_act);
         HIP_TRY(hipGetLastError());
-        // one exchange per iteration: every shard's {record, candidate column}, in place
+        // one collective per iteration: every shard's record (and, without P2P mappings, its candidate column), in place
         NCCL_TRY(g_rccl.AllGather(slot, c->d_xbuf, c->xbuf_slot_words, ncclUint64, c->comm, c->stream));
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, a);
+    } else if (c->n_ranks == 1) {
+        hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(1024), 0, c->stream, a);
+    } else {
+        return fail(UTM_ESTATE, "sharded context without a fused exchange: use utm_local_best / utm_apply_records, or enable the mailboxes / RCCL");
     }
     HIP_TRY(hipGetLastError());
     return UTM_OK;
@@ -951,6 +967,8 @@ static int sync_state(utm_ctx *c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->iter = c->h_st->iter;
     c->captured_seen = c->h_st->tot;
+    c->xseq_host = c->h_st->xseq;
+    if (c->h_st->xerror) return fail(UTM_ECOMM, "a shard's record did not arrive through the mailboxes in time");
     if (c->h_st->all_exact) c->af_all_exact = true;
     c->active_ub = c->h_st->n_active;
     c->finished = c->h_st->done != 0;
@@ -1160,7 +1178,7 @@ extern "C" int utm_local_best(utm_ctx *c, utm_record *rec)
     TRY(enqueue_score(c));
     PickArgs a = pick_args(c);
     enqueue_candidates(c, a);
-    hipLaunchKernelGGL(k_pick<false>, dim3(1), dim3(1024), 0, c->stream, a);
+    hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     const u64 slot = c->xbuf_slot_words;
     HIP_TRY(hipMemcpyAsync(rec, c->d_xbuf + (u64)c->rank * slot, sizeof *rec, hipMemcpyDeviceToHost, c->stream));
@@ -1224,15 +1242,17 @@ extern "C" int utm_apply_records(utm_ctx *c, const utm_record *recs, int32_t n_r
 }
 
 // ---------------------------------------------------------------------------------------- P2P column access
+#define UTM_MAX_RANKS 64
 struct P2PHeader {
-    uint32_t first, n_local, n_chunks, pad;
+    uint32_t first, n_local, n_chunks, has_mbox;
 };
+// blob = header, n_chunks column handles, one mailbox handle
 
 extern "C" int utm_p2p_blob_bytes(utm_ctx *c, uint64_t *n_bytes)
 {
     CTX(c);
     if (!n_bytes) return fail(UTM_EINVAL, "n_bytes is NULL");
-    *n_bytes = sizeof(P2PHeader) + c->chunks.size() * sizeof(hipIpcMemHandle_t);
+    *n_bytes = sizeof(P2PHeader) + (c->chunks.size() + 1) * sizeof(hipIpcMemHandle_t);
     return UTM_OK;
 }
 
@@ -1241,10 +1261,30 @@ extern "C" int utm_p2p_export(utm_ctx *c, void *blob)
     CTX(c);
     if (!blob) return fail(UTM_EINVAL, "blob is NULL");
     if (c->chunks.empty()) return fail(UTM_ESTATE, "no chunks");
-    P2PHeader hd{c->first, c->n_local, (uint32_t)c->chunks.size(), 0};
+    if (!c->d_mbox) {
+        // record mailboxes: uncached device memory so that neither side's caches sit between a peer's store and our poll
+        const size_t bytes = 2 * UTM_MAX_RANKS * sizeof(Mailbox);
+        void *p = nullptr;
+        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess &&
+            hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess)
+            p = nullptr;
+        (void)hipGetLastError();
+        if (p) {
+            c->d_mbox = static_cast<Mailbox *>(p);
+            HIP_TRY(hipMemsetAsync(c->d_mbox, 0, bytes, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    P2PHeader hd{c->first, c->n_local, (uint32_t)c->chunks.size(), c->d_mbox ? 1u : 0u};
     memcpy(blob, &hd, sizeof hd);
     hipIpcMemHandle_t *hs = reinterpret_cast<hipIpcMemHandle_t *>(static_cast<char *>(blob) + sizeof hd);
     for (size_t k = 0; k < c->chunks.size(); ++k) HIP_TRY(hipIpcGetMemHandle(&hs[k], c->chunks[k].cols));
+    memset(&hs[c->chunks.size()], 0, sizeof(hipIpcMemHandle_t));
+    if (c->d_mbox && hipIpcGetMemHandle(&hs[c->chunks.size()], c->d_mbox) != hipSuccess) {
+        (void)hipGetLastError();
+        hd.has_mbox = 0;
+        memcpy(blob, &hd, sizeof hd);
+    }
     return UTM_OK;
 }
 
@@ -1258,6 +1298,11 @@ static void p2p_close(utm_ctx *c)
     }
     (void)hipFree(c->d_peer_first);
     c->d_peer_first = nullptr;
+    for (void *p : c->mbox_opened) (void)hipIpcCloseMemHandle(p);
+    c->mbox_opened.clear();
+    (void)hipFree(c->d_peer_mbox);
+    c->d_peer_mbox = nullptr;
+    c->mbox_ok = false;
     c->p2p = false;
 }
 
@@ -1266,7 +1311,10 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
     CTX(c);
     if (!blobs || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(UTM_EINVAL, "bad rank %d of %d", rank, n_ranks);
     p2p_close(c);
-    const size_t blob = sizeof(P2PHeader) + c->chunks.size() * sizeof(hipIpcMemHandle_t);
+    if (n_ranks > UTM_MAX_RANKS) return fail(UTM_EINVAL, "at most %d shards", UTM_MAX_RANKS);
+    const size_t blob = sizeof(P2PHeader) + (c->chunks.size() + 1) * sizeof(hipIpcMemHandle_t);
+    std::vector<Mailbox *> boxes(n_ranks, nullptr);
+    bool all_boxes = c->d_mbox != nullptr;
     std::vector<unsigned> firsts(n_ranks);
     std::vector<std::vector<const u64 *>> table(c->chunks.size(), std::vector<const u64 *>(n_ranks, nullptr));
     for (int r = 0; r < n_ranks; ++r) {
@@ -1284,6 +1332,20 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
             c->chunks[k].ipc_opened.push_back(p);
             table[k][r] = static_cast<const u64 *>(p);
         }
+        if (r == rank) {
+            boxes[r] = c->d_mbox;
+        } else if (hd.has_mbox && all_boxes) {
+            void *p = nullptr;
+            if (hipIpcOpenMemHandle(&p, hs[c->chunks.size()], hipIpcMemLazyEnablePeerAccess) == hipSuccess) {
+                c->mbox_opened.push_back(p);
+                boxes[r] = static_cast<Mailbox *>(p);
+            } else {
+                (void)hipGetLastError();
+                all_boxes = false;
+            }
+        } else {
+            all_boxes = false;
+        }
     }
     HIP_TRY(hipMalloc(&c->d_peer_first, (size_t)n_ranks * 4));
     HIP_TRY(copy_sync(c, c->d_peer_first, firsts.data(), (size_t)n_ranks * 4, hipMemcpyHostToDevice));
@@ -1291,8 +1353,51 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
         HIP_TRY(hipMalloc(&c->chunks[k].d_peer_cols, (size_t)n_ranks * sizeof(u64 *)));
         HIP_TRY(copy_sync(c, c->chunks[k].d_peer_cols, table[k].data(), (size_t)n_ranks * sizeof(u64 *), hipMemcpyHostToDevice));
     }
+    if (all_boxes) {
+        HIP_TRY(hipMalloc(&c->d_peer_mbox, (size_t)n_ranks * sizeof(Mailbox *)));
+        HIP_TRY(copy_sync(c, c->d_peer_mbox, boxes.data(), (size_t)n_ranks * sizeof(Mailbox *), hipMemcpyHostToDevice));
+    }
     c->p2p = true;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
     c->prepared = false;  // exchange slots shrink to records
+    return UTM_OK;
+}
+
+// One full post + wait round through the mailboxes, four times.  Collective: every shard calls it.  *ok = this
+// shard received every peer's test record in time.  The caller combines the shards' answers and, if all are 1,
+// switches the fused loop to the mailboxes with utm_p2p_use_mailboxes.
+extern "C" int utm_p2p_selftest(utm_ctx *c, int32_t *ok)
+{
+    CTX(c);
+    if (!ok) return fail(UTM_EINVAL, "ok is NULL");
+    *ok = 0;
+    if (!c->p2p || !c->d_peer_mbox) return UTM_OK;  // nothing to test: answer "no"
+    int *d_ok = nullptr;
+    HIP_TRY(hipMalloc(&d_ok, 4));
+    int one = 1;
+    HIP_TRY(copy_sync(c, d_ok, &one, 4, hipMemcpyHostToDevice));
+    for (int round = 0; round < 4; ++round) {
+        c->xseq_host += 1;
+        hipLaunchKernelGGL(k_mbox_ping, dim3(1), dim3(64), 0, c->stream, c->d_mbox, c->d_peer_mbox, c->rank, c->n_ranks,
+                           c->xseq_host, d_ok);
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    int got = 0;
+    if (e == hipSuccess) e = copy_sync(c, &got, d_ok, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_ok);
+    if (e != hipSuccess) return fail(UTM_EHIP, "mailbox self-test: %s", hipGetErrorString(e));
+    *ok = got;
+    c->prepared = false;  // the loop state carries the exchange sequence number
+    return UTM_OK;
+}
+
+extern "C" int utm_p2p_use_mailboxes(utm_ctx *c, int32_t on)
+{
+    CTX(c);
+    if (on && (!c->p2p || !c->d_peer_mbox)) return fail(UTM_ESTATE, "mailboxes are not mapped");
+    c->mbox_ok = on != 0;
+    c->prepared = false;
     return UTM_OK;
 }
 
@@ -1318,11 +1423,14 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     NCCL_TRY(g_rccl.CommInitRank(&c->comm, n_ranks, u, rank));
+    const bool had_p2p = c->p2p;
     c->rank = rank;
     c->n_ranks = n_ranks;
     // Map every rank's columns (hipIpc) so that a winner's column is read in place over xGMI instead of
     // travelling through an all-gather; all ranks must agree, otherwise everyone keeps the all-gather form.
-    if (n_ranks > 1 && !tune_env("UTM_NO_P2P", 0)) {
+    if (n_ranks > 1 && c->p2p && (c->rank != rank || c->n_ranks != n_ranks))
+        return fail(UTM_EINVAL, "P2P mappings were imported as rank %d of %d", c->rank, c->n_ranks);
+    if (n_ranks > 1 && !c->p2p && !tune_env("UTM_NO_P2P", 0)) {  // (mappings may already be in place: utm_p2p_import)
         uint64_t blob = 0;
         TRY(utm_p2p_blob_bytes(c, &blob));
         std::vector<char> mine(blob), all(blob * n_ranks);
@@ -1339,6 +1447,14 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
         TRY(utm_comm_allreduce_max(c, &neg));
         (void)flag;
         if (-neg < 0.5 && c->p2p) p2p_close(c);
+        if (c->p2p && !had_p2p && !tune_env("UTM_NO_MAILBOX", 0)) {
+            // can every shard really see every other shard's mailbox stores?  try it, agree, then drop RCCL from the loop
+            int32_t box_ok = 0;
+            TRY(utm_p2p_selftest(c, &box_ok));
+            double nb = box_ok ? -1.0 : 0.0;
+            TRY(utm_comm_allreduce_max(c, &nb));
+            if (-nb > 0.5) TRY(utm_p2p_use_mailboxes(c, 1));
+        }
     }
     TRY(ensure_xbuf(c, n_ranks));  // c->comm is set: slots carry whole columns unless P2P is on
     c->prepared = false;

@@ -23,6 +23,8 @@ class DeviceMatrix:
         self.n_local = int(self.n_samples - self.first_sample if n_local is None else n_local)
         self.chunk_vars = []
         self.p2p = False
+        self.fused = False      # run() is collective over the shards (mailboxes or RCCL)
+        self.fused_mailboxes = False
         flags = (nat.FLAG_PROFILE_EVENTS if profile_events else 0) | (nat.FLAG_AF_SEQUENTIAL if af_sequential else 0)
         code = nat.lib().utm_ctx_create(int(device), self.n_samples, self.first_sample, self.n_local, flags,
                                         ctypes.byref(self._h))
@@ -204,6 +206,17 @@ class DeviceMatrix:
         nat.check(nat.lib().utm_p2p_import(self._h, int(rank), len(blobs), buf))
         self.p2p = True
 
+    def p2p_selftest(self):
+        """Collective over the shards: can this shard see every peer's mailbox stores?"""
+        ok = ctypes.c_int32(0)
+        nat.check(nat.lib().utm_p2p_selftest(self._h, ctypes.byref(ok)))
+        return bool(ok.value)
+
+    def p2p_use_mailboxes(self, on=True):
+        """After every shard's self-test passed: run() becomes collective, records travel through the mailboxes."""
+        nat.check(nat.lib().utm_p2p_use_mailboxes(self._h, 1 if on else 0))
+        self.fused = self.fused_mailboxes = bool(on)
+
     # -- RCCL
     @staticmethod
     def comm_unique_id():
@@ -214,6 +227,7 @@ class DeviceMatrix:
     def comm_init(self, rank, n_ranks, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), nat.UNIQUE_ID_BYTES)
         nat.check(nat.lib().utm_comm_init(self._h, int(rank), int(n_ranks), buf))
+        self.fused = True
 
     def allreduce_max(self, value):
         v = ctypes.c_double(float(value))

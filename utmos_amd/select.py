@@ -348,19 +348,23 @@ def select_main(cmdargs):
             sys.exit(1)
 
     # one process per GPU (torchrun-style RANK / WORLD_SIZE / LOCAL_RANK): each holds a block of the samples
-    from .sharded import SocketTransport, dist_env, rendezvous_unique_id
+    from .sharded import bootstrap, dist_env, enable_p2p
     rank, world, local_rank = dist_env()
     shard = (rank, world) if world > 1 else None
     dev = local_rank if world > 1 and "--device" not in cmdargs else args.device
     data = load_files(args.in_files, args.lowmem, args.buffer, args.af, dev, shard)
     transport = None
     if world > 1:
-        if os.environ.get("UTMOS_TRANSPORT", "rccl") == "socket":   # host-staged exchange (tests, hosts without RCCL)
-            transport = SocketTransport(rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                                        int(os.environ.get("MASTER_PORT", "29617")) + 1)
-        else:
-            uid, _ = rendezvous_unique_id(rank, device.DeviceMatrix.comm_unique_id)
-            data["data"].comm_init(rank, world, uid)
+        matrix = data["data"]
+        host_only = os.environ.get("UTMOS_TRANSPORT", "rccl") == "socket"     # never touch RCCL (tests, hosts without it)
+        transport, uid = bootstrap(rank, world, None if host_only else device.DeviceMatrix.comm_unique_id)
+        if os.environ.get("UTMOS_P2P", "1") == "1":
+            enable_p2p(matrix, transport)           # hipIpc column mappings + record mailboxes, self-tested
+        if not matrix.fused and not host_only:
+            matrix.comm_init(rank, world, uid)      # RCCL carries the per-iteration exchange instead
+        if matrix.fused:                            # the loop runs on the devices: nothing goes through the host
+            transport.close()
+            transport = None
         if rank != 0:
             args.out = os.devnull
     if not data["has_af"] and args.af:

@@ -59,7 +59,7 @@ class SocketTransport:
     """allgather/broadcast over plain TCP sockets (star through rank 0); no third-party dependency,
     so GPU processes never have to load a second HIP runtime next to libutmos_hip.so."""
 
-    def __init__(self, rank, world, addr="127.0.0.1", port=29617, timeout=300.0):
+    def __init__(self, rank, world, addr="127.0.0.1", port=29617, timeout=300.0, listener=None):
         import socket
         import struct
         import time
@@ -68,9 +68,11 @@ class SocketTransport:
         if world == 1:
             return
         if rank == 0:
-            srv = socket.socket()
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
+            srv = listener            # rank 0 may hand in a socket it already bound (e.g. to an ephemeral port)
+            if srv is None:
+                srv = socket.socket()
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
             srv.listen(world)
             srv.settimeout(timeout)
             by_rank = {}
@@ -158,32 +160,71 @@ def dist_env():
             int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))))
 
 
-def rendezvous_unique_id(rank, make_id, timeout=300.0):
-    """Share rank 0's 128-byte ncclUniqueId through a file every rank of this launch can name
-    (same MASTER_PORT, run id and parent process = the launcher)."""
+def _rendezvous_path():
+    import os
+    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"utmos_amd_rendezvous_{key}")
+
+
+def _publish(path, payload):
+    import os
+    tmp = f"{path}.{os.getpid()}"
+    with open(tmp, "wb") as fh:
+        fh.write(payload)
+    os.replace(tmp, path)
+
+
+def _await(path, n_bytes, rank, timeout):
     import os
     import time
     started = time.time()
-    key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
-    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"utmos_amd_ncclid_{key}")
-    if rank == 0:
-        uid = make_id()
-        tmp = f"{path}.{os.getpid()}"
-        with open(tmp, "wb") as fh:
-            fh.write(uid)
-        os.replace(tmp, path)
-        return uid, path
     while time.time() - started < timeout:
         try:
             if os.path.getmtime(path) >= started - 600:      # never a leftover of an older launch
                 with open(path, "rb") as fh:
-                    uid = fh.read()
-                if len(uid) == 128:
-                    return uid, path
+                    data = fh.read()
+                if len(data) == n_bytes:
+                    return data
         except FileNotFoundError:
             pass
         time.sleep(0.05)
-    raise RuntimeError(f"rank {rank}: no ncclUniqueId at {path} after {timeout:.0f} s")
+    raise RuntimeError(f"rank {rank}: nothing at {path} after {timeout:.0f} s")
+
+
+def rendezvous_unique_id(rank, make_id, timeout=300.0):
+    """Share rank 0's 128-byte ncclUniqueId through a file every rank of this launch can name
+    (same MASTER_PORT, run id and parent process = the launcher)."""
+    path = _rendezvous_path() + "_id"
+    if rank == 0:
+        uid = make_id()
+        _publish(path, uid)
+        return uid, path
+    return _await(path, 128, rank, timeout), path
+
+
+def bootstrap(rank, world, make_id=None, timeout=300.0):
+    """One-node start-up of a one-process-per-GPU launch: rank 0 binds a TCP socket to an ephemeral port and
+    publishes {port, ncclUniqueId} in the launch's rendezvous file; everyone connects.  -> (transport, uid)."""
+    import socket
+    import struct
+    if world == 1:
+        return SocketTransport(0, 1), (make_id() if make_id else None)
+    path = _rendezvous_path() + "_boot"
+    if rank == 0:
+        srv = socket.socket()
+        srv.bind(("127.0.0.1", 0))
+        uid = make_id() if make_id else bytes(128)
+        _publish(path, struct.pack("<i", srv.getsockname()[1]) + uid)
+        transport = SocketTransport(0, world, listener=srv, timeout=timeout)
+        try:
+            import os
+            os.remove(path)
+        except OSError:
+            pass
+        return transport, (uid if make_id else None)
+    data = _await(path, 132, rank, timeout)
+    port = struct.unpack("<i", data[:4])[0]
+    return SocketTransport(rank, world, "127.0.0.1", port, timeout=timeout), (data[4:] if make_id else None)
 
 
 def enable_p2p(shard, transport):
@@ -205,7 +246,12 @@ def enable_p2p(shard, transport):
     everyone = all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0)))
     if not everyone:
         shard.p2p = False   # (a context that imported keeps its mappings but columns are broadcast again)
-    return everyone
+        return False
+    # the mappings exist everywhere: can the shards also exchange their records on the device?
+    boxes = shard.p2p_selftest()
+    if all(r[1] == 1 for r in transport.allgather((0.0, 1 if boxes else 0, 0))):
+        shard.p2p_use_mailboxes(True)   # shard.fused: run() is now collective, nothing goes through the host
+    return True
 
 
 def sharded_greedy(shard, transport, select_count):
