@@ -151,3 +151,35 @@ def test_sharded_protocol_world_size_3_sockets():
     for p in procs:
         p.join(timeout=30)
     assert sorted(r[0] for r in res) == [0, 1, 2] and all(r[1] for r in res)
+
+
+def _bootstrap_worker(rank, world, env, q):
+    os.environ.update(env)
+    from utmos_amd.sharded import bootstrap
+    transport, uid = bootstrap(rank, world, (lambda: bytes(range(128))) if True else None, timeout=60)
+    try:
+        recs = transport.allgather((float(rank), rank, 10 * rank))
+        blobs = transport.allgather_bytes(bytes([rank]) * 5)
+        col = transport.broadcast(np.arange(4, dtype=np.uint64) if rank == 1 else None, 4, 1)
+        q.put((rank, uid == bytes(range(128)), recs, blobs, col.tolist()))
+    finally:
+        transport.close()
+
+
+def test_bootstrap_over_the_rendezvous_file_and_an_ephemeral_port(tmp_path):
+    """One-node start-up used by bench.py / the CLI for N > 1: rank 0 publishes {port, id} in a file named after
+    the launch (MASTER_PORT, run id, parent pid); the others connect."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    env = {"MASTER_PORT": str(45000 + os.getpid() % 1000), "TORCHELASTIC_RUN_ID": "t", "TMPDIR": str(tmp_path)}
+    procs = [ctx.Process(target=_bootstrap_worker, args=(r, 3, env, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert [r[0] for r in res] == [0, 1, 2] and all(r[1] for r in res)
+    assert all(r[2] == [(0.0, 0, 0), (1.0, 1, 10), (2.0, 2, 20)] for r in res)
+    assert all(r[3] == [b"\x00" * 5, b"\x01" * 5, b"\x02" * 5] for r in res)
+    assert all(r[4] == [0, 1, 2, 3] for r in res)
