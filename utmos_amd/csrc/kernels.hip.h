@@ -914,6 +914,25 @@ __device__ void decide(const PickArgs &a)
     if (st->tot >= a.n_var_total) st->done = 1;  // "Ran out of new variants" (select.py:110-112)
 }
 
+// Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
+// landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
+#define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
+__device__ __forceinline__ bool mbox_wait(const Mailbox *slot, u64 expected, Rec *out)
+{
+    for (unsigned spin = 0; spin < UTM_MBOX_SPINS; ++spin) {
+        if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == expected) {
+            out->score = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&slot->score), __ATOMIC_RELAXED,
+                                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+            out->idx = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            out->new_count = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->new_count), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_SYSTEM);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return false;
+}
+
 // MODE 0: single shard -- pick and decide.  1: write this shard's record into its exchange slot.
 // 2: as 1, and post the record into every shard's mailbox (device-side exchange over P2P mappings).
 template <int MODE>
@@ -921,6 +940,7 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
 {
     __shared__ Cand wbest[16];
     __shared__ Rec srec;
+    __shared__ int late;
     IterState *st = a.st;
     if (st->done) return;
     const unsigned n_active = st->n_active;
@@ -974,6 +994,7 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
         rc->new_count = n_active ? best.cnt : 0;
         st->best_pos = best.pos;
         if (MODE == 2) {
+            late = 0;
             srec.score = rc->score;
             srec.idx = rc->idx;
             srec.new_count = rc->new_count;
@@ -1001,6 +1022,19 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
             __hip_atomic_store(reinterpret_cast<u64 *>(&dst->new_count), (u64)srec.new_count, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // ... and collect that shard's record of the same exchange from the local mailbox
+            const Mailbox *slot = a.mbox + (seq & 1) * a.n_ranks + threadIdx.x;
+            if (!mbox_wait(slot, seq, rec_of(a, threadIdx.x))) late = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (late) {
+                st->xerror = 1;  // a shard went away: end the loop, the host reports it
+                st->done = 1;
+            } else {
+                st->xseq += 1;
+                decide(a);
+            }
         }
     }
 }
@@ -1009,49 +1043,6 @@ __global__ void k_decide(PickArgs a)
 {
     if (a.st->done) return;
     if (threadIdx.x == 0) decide(a);
-}
-
-// Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
-// landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
-#define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
-__device__ __forceinline__ bool mbox_wait(const Mailbox *slot, u64 expected, Rec *out)
-{
-    for (unsigned spin = 0; spin < UTM_MBOX_SPINS; ++spin) {
-        if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == expected) {
-            out->score = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&slot->score), __ATOMIC_RELAXED,
-                                                                      __HIP_MEMORY_SCOPE_SYSTEM));
-            out->idx = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            out->new_count = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->new_count), __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_SYSTEM);
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(16);
-    }
-    return false;
-}
-
-__global__ __launch_bounds__(64) void k_wait_decide(PickArgs a)
-{
-    __shared__ int late;
-    IterState *st = a.st;
-    if (st->done) return;
-    if (threadIdx.x == 0) late = 0;
-    __syncthreads();
-    const u64 expected = st->xseq + 1;
-    if ((int)threadIdx.x < a.n_ranks) {
-        const Mailbox *slot = a.mbox + (expected & 1) * a.n_ranks + threadIdx.x;
-        if (!mbox_wait(slot, expected, rec_of(a, threadIdx.x))) late = 1;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (late) {
-            st->xerror = 1;  // a shard went away: end the loop, the host reports it
-            st->done = 1;
-            return;
-        }
-        st->xseq = expected;
-        decide(a);
-    }
 }
 
 // Mailbox self-test (utm_p2p_selftest): one full post + wait round with a recognisable payload.

@@ -938,8 +938,7 @@ static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
     enqueue_candidates(c, a);
     if (c->n_ranks > 1 && c->mbox_ok) {
         // device-side exchange: post this shard's record into every shard's mailbox, wait for theirs, decide
-        hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, c->stream, a);
-        hipLaunchKernelGGL(k_wait_decide, dim3(1), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, c->stream, a);  // pick, post, collect, decide
     } else if (c->comm) {
         hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, c->stream, a);
         u64 *slot = c->d_xbuf + (u64)c->rank * c->xbuf_slot_words;
