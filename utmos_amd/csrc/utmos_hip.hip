@@ -189,11 +189,7 @@ struct utm_ctx {
 };
 
 static inline u64 round_up(u64 x, u64 m) { return (x + m - 1) / m * m; }
-static int tune_env_early(const char *name)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : 0;
-}
+
 
 // How kernels find the previous winner's column.  With P2P the scoring kernels never fuse the update
 // (every workgroup would pull the remote tile over xGMI): k_apply_pending reads the column once instead.
@@ -205,8 +201,7 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
     p.chunk_off = ch.off;
     p.peer_cols = c->p2p ? (const u64 *const *)ch.d_peer_cols : nullptr;
     p.peer_first = c->d_peer_first;
-    static const int no_fuse = tune_env_early("UTM_NO_FUSE");
-    p.fuse = scoring_kernel && !c->p2p && !no_fuse;
+    p.fuse = scoring_kernel && !c->p2p;
     return p;
 }
 
@@ -802,8 +797,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
         c->ev_used += 2;
     };
     const bool seq_path = c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential);
-    static const int no_fuse = tune_env_early("UTM_NO_FUSE");
-    if ((c->p2p || no_fuse) && !seq_path)  // the scoring kernels do not fuse the update here: read the winner's column once
+    if (c->p2p && !seq_path)  // the scoring kernels do not fuse the update here: read the winner's column once
         for (auto &ch : c->chunks)
             hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
                                ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
