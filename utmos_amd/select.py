@@ -35,19 +35,21 @@ STORE_SUFFIX = ".utm"
 def calculate_scores(matrix, sample_mask, sample_weights=None):
     """Best scoring sample for the given mask: (column index, new_variant_count) or (None, None).
 
-    Stateless like the reference: covered variants are recomputed from sample_mask == 0.  The greedy
-    driver below does not call this per iteration (it keeps the loop on the device); it is the drop-in
-    for callers that do.
+    Stateless like the reference: covered variants are recomputed from sample_mask == 0.  Scoring, masking,
+    weighting and the first-maximum argmax all run on the device (utm_local_best); nothing is selected.  The
+    greedy driver below does not call this per iteration (it keeps the whole loop on the device); it is the
+    drop-in for callers that do.
     """
-    matrix.set_state(np.asarray(sample_mask))
+    sample_mask = np.asarray(sample_mask)
+    matrix.set_state(sample_mask)
     matrix.set_weights(sample_weights)
-    counts, scores = matrix.peek_scores()
-    full = np.zeros(matrix.n_samples)
-    full[matrix.first_sample:matrix.first_sample + matrix.n_local] = scores
-    use_sample = np.argmax(full)
-    if full[use_sample] == 0:
+    matrix.reset()
+    score, use_sample, new_variant_count = matrix.local_best()
+    # np.argmax runs over every sample and masked ones hold 0 (select.py:43-48): a best of 0, or a negative best
+    # while some sample is masked, means "nothing to select"
+    if use_sample < 0 or score == 0 or (score < 0 and (sample_mask != 1).any()):
         return None, None
-    return use_sample, counts[use_sample - matrix.first_sample]
+    return np.int64(use_sample), np.int64(new_variant_count)
 
 
 def is_memsafe(shape, with_af=False):
