@@ -117,13 +117,18 @@ def _cli_rank(rank, world, port, argv, q):
         q.put((rank, repr(e)))
 
 
-@pytest.mark.parametrize("name", ["select_multi", "select_af", "select_weights_subset"])
+@pytest.mark.parametrize("name", ["select_multi", "select_af", "select_weights_subset", "select_first:store"])
 def test_cli_two_processes_sharded_over_samples(name, tmp_path):
-    """`utmos select` as one process per shard (here both on the box's single GPU, host-staged exchange):
-    rank 0 writes the golden TSV."""
+    """`utmos select` as one process per shard (here both on the box's single GPU; socket start-up, then the
+    device-side exchange): rank 0 writes the golden TSV.  `:store` = the shards load a packed .utm store."""
     import multiprocessing as mp
     import os
+    name, _, from_store = name.partition(":")
     argv, out = cli_args(CASES[name], tmp_path)
+    if from_store:
+        store = str(tmp_path / "m.utm")
+        run_cli(argv + ["--lowmem", store])                   # single process writes the store
+        argv = ["-o", out, "--lowmem", store]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 35500 + os.getpid() % 2000

@@ -192,7 +192,7 @@ def load_store(path, dev=0, shard=None):
             matrix.upload_columns(idx, z[f"cols{c}"][lo:hi])
             if has_af:
                 matrix.set_af(idx, z[f"af{c}"])
-        return {"samples": samples, "data": matrix, "var_count": z["var_count"], "has_af": has_af}
+        return {"samples": samples, "data": matrix, "var_count": z["var_count"][lo:hi], "has_af": has_af}
 
 
 # pylint: disable=too-many-locals
@@ -220,15 +220,11 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0, shard=
         if samples is None:
             samples = np.asarray(dat["samples"]).astype("U")
             matrix = _shard_matrix(len(samples), dev, shard)
-            host_var_count = np.zeros(len(samples), dtype=np.int64)
         rows = np.ascontiguousarray(dat["GT"], dtype=np.uint8)
         informative = rows.any(axis=1)          # a row without carriers has no set bit in any byte
         logging.debug("fitering %d uninformative variants", int((~informative).sum()))
         rows = rows[informative]
         af = np.asarray(dat["AF"], dtype=np.float64).reshape(-1)[informative]
-        if sharded:     # every shard reports var_count for all samples: counted on the host from the packed rows
-            for lo in range(0, len(rows), 65536):
-                host_var_count += np.unpackbits(rows[lo:lo + 65536], axis=1, count=len(samples)).sum(axis=0, dtype=np.int64)
         # one chunk per `step` variants: everything in one chunk unless the estimate says otherwise
         step = len(rows) if (MAXMEM != 0 and is_memsafe((len(rows), len(samples)), calc_af)) else max(64, buffer // 64 * 64)
         for lo in range(0, len(rows), step):
@@ -239,8 +235,9 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0, shard=
         logging.debug("Loaded %d of %d", load_count + 1, len(in_files))
 
     ret = {"samples": samples, "data": matrix}
-    # before AF == 0 rows are cleared, like select.py:281-284
-    ret["var_count"] = host_var_count if sharded else matrix.var_count()
+    # before AF == 0 rows are cleared, like select.py:281-284.  (A shard counts its own samples; select_main
+    # gathers the shards' parts.)
+    ret["var_count"] = matrix.var_count()
     if calc_af:
         as32 = lowmem is not None
         for chunk, af in enumerate(af_parts):
@@ -339,6 +336,23 @@ def parse_args(args):
     return args
 
 
+def _padded(local_counts, world, n_samples):
+    """Shards differ by at most one sample: pad to a common length for the fixed-size exchange."""
+    width = (n_samples + world - 1) // world
+    out = np.full(width, -1, dtype=np.int64)
+    out[:len(local_counts)] = local_counts
+    return out
+
+
+def _unpadded(parts, world, n_samples):
+    from .sharded import shard_bounds
+    chunks = []
+    for rank, blob in enumerate(parts):
+        n_local = shard_bounds(n_samples, rank, world)[1]
+        chunks.append(np.frombuffer(blob, dtype=np.int64)[:n_local])
+    return np.concatenate(chunks)
+
+
 def select_main(cmdargs):
     """Main"""
     global MAXMEM  # pylint: disable=global-statement
@@ -360,6 +374,9 @@ def select_main(cmdargs):
         matrix = data["data"]
         host_only = os.environ.get("UTMOS_TRANSPORT", "rccl") == "socket"     # never touch RCCL (tests, hosts without it)
         transport, uid = bootstrap(rank, world, None if host_only else device.DeviceMatrix.comm_unique_id)
+        # var_count of every sample, for the output rows: each shard popcounts its own columns on its GPU
+        parts = transport.allgather_bytes(np.ascontiguousarray(_padded(data["var_count"], world, len(data["samples"]))).tobytes())
+        data["var_count"] = _unpadded(parts, world, len(data["samples"]))
         if os.environ.get("UTMOS_P2P", "1") == "1":
             enable_p2p(matrix, transport)           # hipIpc column mappings + record mailboxes, self-tested
         if not matrix.fused and not host_only:
