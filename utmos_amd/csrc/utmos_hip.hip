@@ -1416,18 +1416,25 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
     NCCL_TRY(g_rccl.CommInitRank(&c->comm, n_ranks, u, rank));
-    const bool had_p2p = c->p2p;
+    if (c->p2p && (c->rank != rank || c->n_ranks != n_ranks))
+        return fail(UTM_EINVAL, "P2P mappings were imported as rank %d of %d", c->rank, c->n_ranks);
     c->rank = rank;
     c->n_ranks = n_ranks;
-    // Map every rank's columns (hipIpc) so that a winner's column is read in place over xGMI instead of
-    // travelling through an all-gather; all ranks must agree, otherwise everyone keeps the all-gather form.
-    if (n_ranks > 1 && c->p2p && (c->rank != rank || c->n_ranks != n_ranks))
-        return fail(UTM_EINVAL, "P2P mappings were imported as rank %d of %d", c->rank, c->n_ranks);
-    if (n_ranks > 1 && !c->p2p && !tune_env("UTM_NO_P2P", 0)) {  // (mappings may already be in place: utm_p2p_import)
+    // true only if `mine` is true on every rank (collective)
+    auto everywhere = [&](bool mine, bool *all) -> int {
+        double bad = mine ? 0.0 : 1.0;
+        TRY(utm_comm_allreduce_max(c, &bad));
+        *all = bad < 0.5;
+        return UTM_OK;
+    };
+    // Unless the caller already did it (utm_p2p_import), map every rank's columns and record mailboxes (hipIpc):
+    // a winner's column is then read in place over xGMI and the records travel through the mailboxes.  Every step
+    // is agreed on by all ranks; whatever cannot be set up everywhere is left to RCCL.
+    if (n_ranks > 1 && !c->p2p && !tune_env("UTM_NO_P2P", 0)) {
         uint64_t blob = 0;
         TRY(utm_p2p_blob_bytes(c, &blob));
         std::vector<char> mine(blob), all(blob * n_ranks);
-        int ok = utm_p2p_export(c, mine.data()) == UTM_OK;
+        bool ok = utm_p2p_export(c, mine.data()) == UTM_OK;
         char *d_all = nullptr;
         HIP_TRY(hipMalloc(&d_all, blob * n_ranks));
         HIP_TRY(copy_sync(c, d_all + blob * rank, mine.data(), blob, hipMemcpyHostToDevice));
@@ -1436,17 +1443,15 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
         HIP_TRY(copy_sync(c, all.data(), d_all, blob * n_ranks, hipMemcpyDeviceToHost));
         (void)hipFree(d_all);
         if (ok) ok = utm_p2p_import(c, rank, n_ranks, all.data()) == UTM_OK;
-        double flag = ok ? 1.0 : 0.0, neg = -flag;   // min over ranks = -max(-flag)
-        TRY(utm_comm_allreduce_max(c, &neg));
-        (void)flag;
-        if (-neg < 0.5 && c->p2p) p2p_close(c);
-        if (c->p2p && !had_p2p && !tune_env("UTM_NO_MAILBOX", 0)) {
-            // can every shard really see every other shard's mailbox stores?  try it, agree, then drop RCCL from the loop
+        bool mapped = false;
+        TRY(everywhere(ok, &mapped));
+        if (!mapped && c->p2p) p2p_close(c);
+        if (mapped && !tune_env("UTM_NO_MAILBOX", 0)) {
             int32_t box_ok = 0;
-            TRY(utm_p2p_selftest(c, &box_ok));
-            double nb = box_ok ? -1.0 : 0.0;
-            TRY(utm_comm_allreduce_max(c, &nb));
-            if (-nb > 0.5) TRY(utm_p2p_use_mailboxes(c, 1));
+            TRY(utm_p2p_selftest(c, &box_ok));  // can this rank see every peer's mailbox stores?
+            bool boxes = false;
+            TRY(everywhere(box_ok != 0, &boxes));
+            if (boxes) TRY(utm_p2p_use_mailboxes(c, 1));
         }
     }
     TRY(ensure_xbuf(c, n_ranks));  // c->comm is set: slots carry whole columns unless P2P is on
