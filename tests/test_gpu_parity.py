@@ -585,3 +585,21 @@ def test_randomised_configurations_against_the_oracle(dev):
         except AssertionError as e:
             raise AssertionError(f"trial {trial}: n_var={n_var} n_samp={n_samp} density={density} mode={mode} "
                                  f"chunks={chunks} k={k} decr={decr} weights={'yes' if weights is not None else 'no'}") from e
+
+
+def test_generator_and_scoring_do_not_depend_on_the_chunk_layout_at_large_sizes(dev):
+    """20M variants x 15,000 samples (37.5 GB; words x samples x 256 exceeds 2^32, HIP's per-dimension thread limit,
+    which once truncated the generator's launch): one chunk and three chunks must hold the same matrix and give
+    the same rows."""
+    n_var, n_samp = 20_000_000, 15_000
+    out = []
+    for bounds in ([0, n_var], [0, 6_400_000, 13_000_064, n_var]):
+        with dev.DeviceMatrix(n_samp) as m:
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                m.synth_fill(m.add_chunk(hi - lo), seed=4, first_var_global=lo)
+            vc = m.var_count()
+            idx, new, _ = m.run(5)
+            out.append((vc, idx.tolist(), new.tolist()))
+    assert (out[0][0] == out[1][0]).all() and out[0][1:] == out[1][1:]
+    assert out[0][0].min() > 0 and out[0][2][0] == out[0][0].max()      # every sample has data; first gain = largest column
+    assert abs(out[0][0].sum() / (n_var * n_samp) - 0.11) < 0.03           # the generator's mean density (14 octaves)

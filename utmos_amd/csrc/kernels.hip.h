@@ -1150,25 +1150,27 @@ __global__ __launch_bounds__(256) void k_col_popcount(const u64 *__restrict__ co
     if (threadIdx.x == 0) out[s] += part[0] + part[1] + part[2] + part[3];
 }
 
-// Synthetic chunk contents: thread = one word (64 variants) of one local sample.
+// Synthetic chunk contents: thread = one word (64 variants) of one local sample.  Grid = (word blocks,
+// min(samples, 65535)); the samples are strided over grid.y -- a 1-D grid of words x samples would exceed
+// HIP's 2^32 threads per grid dimension on large chunks and be silently truncated.
 __global__ __launch_bounds__(256) void k_synth(u64 *__restrict__ cols, u64 wp, u64 n_var, u64 first_var_global,
                                                u64 seed, unsigned n_total, unsigned first_sample, unsigned octaves,
-                                               u64 words_per_col)
+                                               u64 words_per_col, unsigned n_local)
 {
-    const u64 blocks_per_col = (words_per_col + 255) / 256;
-    const unsigned s = (unsigned)(blockIdx.x / blocks_per_col);
-    const u64 w = (blockIdx.x % blocks_per_col) * 256 + threadIdx.x;
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
     if (w >= words_per_col) return;
-    const unsigned sg = first_sample + s;
-    const u64 skey = utm_sample_key(sg);
-    u64 word = 0;
-    for (int b = 0; b < 64; ++b) {
-        const u64 v = w * 64 + b;
-        if (v >= n_var) break;
-        const u64 key = utm_var_key(seed, first_var_global + v);
-        const unsigned thr = utm_var_threshold(key, octaves);
-        const unsigned forced = utm_var_forced(key, n_total);
-        word |= (u64)utm_cell(key, thr, forced, skey, sg) << b;
+    for (unsigned s = blockIdx.y; s < n_local; s += gridDim.y) {
+        const unsigned sg = first_sample + s;
+        const u64 skey = utm_sample_key(sg);
+        u64 word = 0;
+        for (int b = 0; b < 64; ++b) {
+            const u64 v = w * 64 + b;
+            if (v >= n_var) break;
+            const u64 key = utm_var_key(seed, first_var_global + v);
+            const unsigned thr = utm_var_threshold(key, octaves);
+            const unsigned forced = utm_var_forced(key, n_total);
+            word |= (u64)utm_cell(key, thr, forced, skey, sg) << b;
+        }
+        cols[(u64)s * wp + w] = word;
     }
-    cols[(u64)s * wp + w] = word;
 }

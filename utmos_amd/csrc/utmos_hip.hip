@@ -414,10 +414,10 @@ extern "C" int utm_synth_fill(utm_ctx *c, int32_t chunk, uint64_t seed, uint64_t
     Chunk *ch;
     TRY(chunk_of(c, chunk, &ch));
     const u64 blocks_per_col = (ch->w + 255) / 256;
-    const u64 blocks = blocks_per_col * c->n_local;
-    if (blocks > 0x7FFFFFFFull) return fail(UTM_EINVAL, "chunk too large for one generator launch");
-    hipLaunchKernelGGL(k_synth, dim3((unsigned)blocks), dim3(256), 0, c->stream, ch->cols, ch->wp, ch->n_var,
-                       (u64)first_var_global, (u64)seed, c->n_total, c->first, utm_octaves(c->n_total), ch->w);
+    if (blocks_per_col * 256 >= (1ull << 32)) return fail(UTM_EINVAL, "chunk too large for the generator");
+    const dim3 grid((unsigned)blocks_per_col, std::min(c->n_local, 65535u));
+    hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, c->stream, ch->cols, ch->wp, ch->n_var, (u64)first_var_global, (u64)seed,
+                       c->n_total, c->first, utm_octaves(c->n_total), ch->w, c->n_local);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->prepared = false;
