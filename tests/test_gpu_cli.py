@@ -166,3 +166,18 @@ def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path):
     assert line["sharded_rows_match_single_gpu"] is True
     assert "mailboxes" in line["config"]["sharding"]
     assert line["config"]["iterations_per_step"] == 301
+
+
+def test_cli_input_without_any_carrier_writes_only_the_header(tmp_path):
+    """Every row uninformative (dropped at ingest, select.py:276-279): zero variants, no selection, header only."""
+    import numpy as np
+    part = ou.load_part("tiny")
+    empty = str(tmp_path / "empty.npz")
+    np.savez(empty, GT=np.zeros_like(part["GT"]), AF=part["AF"], samples=part["samples"])
+    out = str(tmp_path / "o.txt")
+    run_cli(["-c", "5", "-o", out, empty])
+    assert open(out).read() == "sample\tvar_count\tnew_count\ttot_captured\tpct_captured\n"
+    # and mixed with a real part it changes nothing
+    real = os.path.join(ou.GOLD, "tiny.npz")
+    run_cli(["-c", "20", "-o", out, empty, real])
+    assert open(out).read() == ou.golden_text(CASES["select_tiny"])

@@ -77,6 +77,9 @@ def greedy_select(matrix, total_variant_count, select_count, vcf_samples, sample
     """
     num_vars = matrix.shape[0]
     tot_captured = 0
+    if num_vars == 0:      # nothing informative was loaded: the reference's first scoring pass finds only zeros
+        logging.warning("Ran out of new variants (multi-allelics)")
+        return
     matrix.set_state(np.asarray(sample_mask))
     matrix.set_weights(sample_weights)
     matrix.reset()
@@ -226,8 +229,10 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0, shard=
         rows = rows[informative]
         af = np.asarray(dat["AF"], dtype=np.float64).reshape(-1)[informative]
         # one chunk per `step` variants: everything in one chunk unless the estimate says otherwise
+        if len(rows) == 0:
+            continue                            # a part without a single carrier contributes nothing
         step = len(rows) if (MAXMEM != 0 and is_memsafe((len(rows), len(samples)), calc_af)) else max(64, buffer // 64 * 64)
-        for lo in range(0, len(rows), step):
+        for lo in range(0, len(rows), max(step, 1)):
             part = rows[lo:lo + step]
             chunk = matrix.add_chunk(len(part))
             matrix.upload_rows_packed(chunk, part)
@@ -237,7 +242,7 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0, shard=
     ret = {"samples": samples, "data": matrix}
     # before AF == 0 rows are cleared, like select.py:281-284.  (A shard counts its own samples; select_main
     # gathers the shards' parts.)
-    ret["var_count"] = matrix.var_count()
+    ret["var_count"] = matrix.var_count() if matrix.chunk_vars else np.zeros(matrix.n_local, dtype=np.int64)
     if calc_af:
         as32 = lowmem is not None
         for chunk, af in enumerate(af_parts):
