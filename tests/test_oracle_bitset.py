@@ -62,3 +62,44 @@ def test_ties_pick_lowest_index_and_excluded_never_cover():
     state = np.array([1, 1, 1, 2], np.uint8)
     idx, new, _ = ou.c_greedy(npo.pack_columns(dense), 6, state)
     assert idx.tolist() == [1, 0] and new.tolist() == [3, 1]
+
+
+def test_fixture_provenance_static_jl_reader():
+    """tests/golden/chunk*.npz are what tools/jl_static.py (opcode walk, nothing unpickled) reads out of the
+    reference's own .jl fixtures -- checked whenever the reference tree is present (build container only)."""
+    import os
+    import sys
+    ref = "/root/reference/repo_utils/test_files"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    sys.path.insert(0, os.path.join(ou.ROOT, "tools"))
+    from jl_static import read_jl
+    for name in ("chunk0", "chunk1", "chunk2"):
+        d = read_jl(os.path.join(ref, name + ".jl"))
+        p = ou.load_part(name)
+        assert (d["GT"] == p["GT"]).all() and (d["AF"].reshape(-1) == p["AF"]).all()
+        assert (np.asarray(d["samples"], dtype=str) == p["samples"]).all()
+
+
+def test_hypothesis_c_oracle_equals_numpy_oracle():
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 300), st.integers(1, 40), st.integers(0, 2 ** 31), st.sampled_from(["int", "w", "af32", "af64"]))
+    def run(n_var, n_samp, seed, mode):
+        rng = np.random.default_rng(seed)
+        dense = rng.random((n_var, n_samp)) < rng.choice([0.02, 0.2, 0.6])
+        state = rng.choice([1, 1, 1, 0, 2], n_samp).astype(np.uint8)
+        weights = rng.choice([-1.0, 0.0, 0.5, 1.0, 2.0], n_samp) if mode == "w" else None
+        af, af_dtype = None, "f64"
+        if mode.startswith("af"):
+            af = rng.random(n_var)
+            af[rng.random(n_var) < 0.1] = 0.0
+            if mode == "af32":
+                af, af_dtype = af.astype(np.float32), "f32"
+        k = int(rng.integers(1, n_samp + 1))
+        exp_idx, exp_new = run_np(dense, state, weights, af, af_dtype, k)
+        idx, new, _ = ou.c_greedy(npo.pack_columns(dense), n_var, state, weights, af, k_max=k)
+        assert idx.tolist() == exp_idx and new.tolist() == exp_new
+
+    run()
