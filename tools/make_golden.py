@@ -6,7 +6,7 @@ are the only thing that travels to the GPU box.  Data only: packed genotype byte
 values, sample names, the reference's expected TSVs and its three small option files.
 
   * chunk{0,1,2}.jl  -> chunk{0,1,2}.npz   via tools/jl_static.py (opcode walk, no unpickling)
-  * chunk_tiny.vcf   -> tiny.npz           via tools/vcf_text.py  (text parse)
+  * chunk_tiny.vcf   -> tiny.npz           via utmos_amd/vcfio.py (text parse)
   * answer_key/*.txt -> answer_key/*.txt   the goldens the reference's suite actually uses
                                            (repo_utils/utmos_ssshtests.sh:81-235)
   * weights.txt / subset.txt / exclude.txt copied (data)
@@ -23,8 +23,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from jl_static import read_jl          # noqa: E402
-from vcf_text import read_vcf_text     # noqa: E402
+sys.path.insert(0, os.path.join(HERE, ".."))
+from jl_static import read_jl                              # noqa: E402
+from utmos_amd.vcfio import read_vcf as read_vcf_text      # noqa: E402  (the build's own text VCF reader)
 
 REF = "/root/reference/repo_utils"
 OUT = os.path.join(HERE, "..", "tests", "golden")

@@ -767,101 +767,124 @@ static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsig
                            pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
 }
 
-// Enqueue the scoring of one iteration for every chunk (and the pending covered update).
-static int enqueue_score(utm_ctx *c, bool force_sequential = false)
+// HIP-event bracket around one scoring launch (UTM_FLAG_PROFILE_EVENTS); a no-op otherwise.
+struct LaunchTimer {
+    utm_ctx *c;
+    bool on;
+    explicit LaunchTimer(utm_ctx *ctx) : c(ctx), on(ctx->flags & UTM_FLAG_PROFILE_EVENTS)
+    {
+        if (!on) return;
+        if (c->ev_used + 2 > c->ev.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            c->ev.push_back(a);
+            c->ev.push_back(b);
+        }
+        (void)hipEventRecord(c->ev[c->ev_used], c->stream);
+    }
+    ~LaunchTimer()
+    {
+        c->score_launches += 1;
+        if (!on) return;
+        (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
+        c->ev_used += 2;
+    }
+};
+
+static void launch_apply_pending(utm_ctx *c)
 {
-    const unsigned a_ub = std::max(1u, c->active_ub);
+    for (auto &ch : c->chunks)
+        hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                           ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
+}
+
+// Sequential AF scoring of every selectable sample: covered is brought up to date first, then one lane per
+// sample walks all chunks in order.
+static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
+{
+    launch_apply_pending(c);
+    LaunchTimer t(c);
+    const unsigned blocks = (a_ub + 63) / 64;
+    if (c->af_mode == UTM_AF_F32)
+        hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                           c->d_act, c->d_cnt, c->d_fscore, 0);
+    else
+        hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                           c->d_act, c->d_cnt, c->d_fscore, 0);
+}
+
+// AF, dense phase: LDS AF tiles.  Every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache), so
+// the groups hold >= 64 samples.
+static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
+{
+    static const int af_target = tune_env("UTM_AF_TARGET_WGS", 16384);
+    const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
+    unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)af_target / std::max<u64>(1, tiles)));
+    const unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
+    n_groups = (a_ub + group - 1) / group;
+    LaunchTimer t(c);
+    hipLaunchKernelGGL(k_score_afq, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
+                       ch.af32, 150 - c->af_q, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, group, n_groups);
+}
+
+// The streaming kernels (k_score_int, k_score_afs): grid = variant tiles x groups of samples.  Tile = the largest
+// of {32 (AF: 16), 8, 2} KiB that still yields >= UTM_MIN_WGS workgroups; group size such that the grid has about
+// UTM_TARGET_WGS workgroups (>> 256 CUs, small enough units for an even tail), at least one sample per wave.
+static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub)
+{
     static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
     static const int min_wgs = tune_env("UTM_MIN_WGS", 1024);
     static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
     static const int use_nt = tune_env("UTM_NT_LOADS", 1);
-    const bool profile = c->flags & UTM_FLAG_PROFILE_EVENTS;
-    // AF: dense phase -> LDS-tile kernel, sparse phase -> streaming kernel with global AF gathers.  The
-    // captured fraction is known from the last batch sync (identical on every shard).
-    const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
-    const double af_switch = sw && *sw ? atof(sw) : 0.2;
-    const bool af_sparse = c->af_mode != UTM_AF_NONE && c->af_fixed && c->n_var_total > 0 &&
-                           (double)c->captured_seen >= af_switch * (double)c->n_var_total;
-    auto ev_begin = [&]() {
-        if (!profile) return;
-        if (c->ev_used + 2 > c->ev.size()) {
-            hipEvent_t a, b;
-            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-            c->ev.push_back(a); c->ev.push_back(b);
-        }
-        (void)hipEventRecord(c->ev[c->ev_used], c->stream);
-    };
-    auto ev_end = [&]() {
-        if (!profile) return;
-        (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
-        c->ev_used += 2;
-    };
-    const bool seq_path = c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential);
-    if (c->p2p && !seq_path)  // the scoring kernels do not fuse the update here: read the winner's column once
-        for (auto &ch : c->chunks)
-            hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
-                               ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
-    if (seq_path) {
-        // sequential chain: update covered first, then one lane per sample over all chunks
-        for (auto &ch : c->chunks)
-            hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
-                               ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
-        ev_begin();
-        const unsigned blocks = (a_ub + 63) / 64;
-        if (c->af_mode == UTM_AF_F32)
-            hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                               c->d_act, c->d_cnt, c->d_fscore, 0);
-        else
-            hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                               c->d_act, c->d_cnt, c->d_fscore, 0);
-        ev_end();
-        c->score_launches += 1;
-    } else {
-        for (auto &ch : c->chunks) {
-            ev_begin();
-            if (c->af_mode != UTM_AF_NONE && !af_sparse) {
-                const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
-                // every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache): groups of >= 64 samples
-                static const int af_target = tune_env("UTM_AF_TARGET_WGS", 16384);
-                unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)af_target / std::max<u64>(1, tiles)));
-                unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
-                n_groups = (a_ub + group - 1) / group;
-                hipLaunchKernelGGL(k_score_afq, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                                   ch.af32, 150 - c->af_q, pending_of(c, ch, true), c->d_st, c->d_act,
-                                   c->d_cnt, c->d_afsum, group, n_groups);
-            } else {
-                const u64 steps_total = ch.wp / UTM_STEP_WORDS;
-                const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
-                int steps = 2;
-                static const int af_big = tune_env("UTM_AF_STEPS", 16) == 32 ? 32 : 16;
-                const int big = c->af_mode != UTM_AF_NONE ? af_big : 32;  // the AF kernel shares LDS with its bit queues
-                for (int cand : {big, 8}) {
-                    const u64 tiles = (steps_total + cand - 1) / cand;
-                    if (tiles * waves_needed >= (u64)min_wgs) { steps = cand; break; }
-                }
-                if (c->af_mode == UTM_AF_NONE && (force_steps == 32 || force_steps == 8 || force_steps == 2)) steps = force_steps;
-                const u64 tiles = (steps_total + steps - 1) / steps;
-                u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
-                group = std::max<u64>(4, (group + 3) / 4 * 4);
-                const unsigned n_groups = (unsigned)((a_ub + group - 1) / group);
-                const unsigned blocks = (unsigned)round_up(tiles * n_groups, 8);  // XCD-aware map: tile_of_block()
-                if (c->af_mode != UTM_AF_NONE) {
-                    const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
-                    const int eb = 150 - c->af_q;
-#define UTM_LAUNCH_AFG(S, Q)                                                                                              \
+    static const int af_big = tune_env("UTM_AF_STEPS", 16) == 32 ? 32 : 16;
+    const bool af = c->af_mode != UTM_AF_NONE;
+    const u64 steps_total = ch.wp / UTM_STEP_WORDS;
+    const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
+    int steps = 2;
+    for (int cand : {af ? af_big : 32, 8}) {  // (the AF kernel shares LDS with its bit queues)
+        const u64 tiles = (steps_total + cand - 1) / cand;
+        if (tiles * waves_needed >= (u64)min_wgs) { steps = cand; break; }
+    }
+    if (!af && (force_steps == 32 || force_steps == 8 || force_steps == 2)) steps = force_steps;
+    const u64 tiles = (steps_total + steps - 1) / steps;
+    u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
+    group = std::max<u64>(4, (group + 3) / 4 * 4);
+    const unsigned n_groups = (unsigned)((a_ub + group - 1) / group);
+    const unsigned blocks = (unsigned)round_up(tiles * n_groups, 8);  // XCD-aware map: tile_of_block()
+    LaunchTimer t(c);
+    if (af) {
+        const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
+        const int eb = 150 - c->af_q;
+#define UTM_LAUNCH_AFS(S, Q)                                                                                              \
     hipLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb,   \
                        pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups)
-                    if (steps == 32) UTM_LAUNCH_AFG(32, 8);       // queue depth per lane
-                    else if (steps == 16) UTM_LAUNCH_AFG(16, 16);
-                    else if (steps == 8) UTM_LAUNCH_AFG(8, 16);
-                    else UTM_LAUNCH_AFG(2, 16);
-#undef UTM_LAUNCH_AFG
-                } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
-                else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
-                else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
-            }
-            ev_end();
-            c->score_launches += 1;
+        if (steps == 32) UTM_LAUNCH_AFS(32, 8);  // second argument: queue depth per lane
+        else if (steps == 16) UTM_LAUNCH_AFS(16, 16);
+        else if (steps == 8) UTM_LAUNCH_AFS(8, 16);
+        else UTM_LAUNCH_AFS(2, 16);
+#undef UTM_LAUNCH_AFS
+    } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+}
+
+// Enqueue the scoring of one iteration for every chunk (and the pending covered update).
+static int enqueue_score(utm_ctx *c, bool force_sequential = false)
+{
+    const unsigned a_ub = std::max(1u, c->active_ub);
+    if (c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential)) {
+        launch_score_sequential(c, a_ub);
+    } else {
+        // AF: dense phase -> LDS-tile kernel, afterwards the streaming kernel.  The captured fraction is known from
+        // the last batch sync (identical on every shard).
+        const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
+        const double af_switch = sw && *sw ? atof(sw) : 0.2;
+        const bool af_dense = c->af_mode != UTM_AF_NONE && (double)c->captured_seen < af_switch * (double)c->n_var_total;
+        if (c->p2p) launch_apply_pending(c);  // the scoring kernels do not fuse the update here: read the winner's column once
+        for (auto &ch : c->chunks) {
+            if (af_dense) launch_score_af_dense(c, ch, a_ub);
+            else launch_score_streaming(c, ch, a_ub);
         }
     }
     HIP_TRY(hipGetLastError());
