@@ -357,12 +357,16 @@ __device__ __forceinline__ u64 af_fixed(unsigned f, int e_base)
 
 // CAP = queue depth per LANE: every lane keeps its own little queue (slot-major in LDS, so a wave's
 // pushes are conflict free) -- no cross-lane prefix sum is needed to place an entry.
+// delta_mask == nullptr: full scoring against ~covered (adds to the accumulators, fuses the pending update).
+// delta_mask != nullptr: *delta* scoring -- the mask holds the variants the last winner newly covered
+// (k_newly_mask made it and already updated covered); their contribution is SUBTRACTED from the persistent
+// accumulators.  Same bytes streamed, but only the few newly covered bits take the queue/gather path.
 template <int STEPS, int CAP>
 __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const unsigned *__restrict__ afbits, int e_base, const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
-                                                   unsigned n_groups)
+                                                   unsigned n_groups, const u64 *__restrict__ delta_mask)
 {
     __shared__ v4u live[STEPS * 64];
     __shared__ unsigned queue[4][CAP][64];
@@ -372,16 +376,21 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
     const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
-    v4u *cv = reinterpret_cast<v4u *>(covered + w0);
-    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
-    const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
-    for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
-        v4u c = cv[i];
-        if (wc) {
-            c |= wc[i];
-            if (grp == 0) cv[i] = c;
+    if (delta_mask) {
+        const v4u *mk = reinterpret_cast<const v4u *>(delta_mask + w0);
+        for (int i = threadIdx.x; i < nsteps * 64; i += 256) live[i] = mk[i];
+    } else {
+        v4u *cv = reinterpret_cast<v4u *>(covered + w0);
+        const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
+        const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
+        for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
+            v4u c = cv[i];
+            if (wc) {
+                c |= wc[i];
+                if (grp == 0) cv[i] = c;
+            }
+            live[i] = ~c;
         }
-        live[i] = ~c;
     }
     __syncthreads();
 
@@ -454,9 +463,9 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
         const unsigned n = wave_sum_u32(acc);
         if (n) {  // wave uniform
             const i64 total = wave_sum_u63(sum);
-            if (lane == 0) {
-                atomicAdd(&cnt[s], (u64)n);
-                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), (u64)total);
+            if (lane == 0) {  // two's complement: adding the negated value subtracts
+                atomicAdd(&cnt[s], delta_mask ? (u64)0 - (u64)n : (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), delta_mask ? (u64)0 - (u64)total : (u64)total);
             }
         }
     }
@@ -545,6 +554,24 @@ __global__ __launch_bounds__(256) void k_newly(u64 *__restrict__ covered, const 
             list_val[slot] = x;
             covered[w] = c | x;
         }
+    }
+}
+
+// Dense form for the streamed delta scoring: mask[w] = the bits of word w the pending winner newly covers
+// (0 where none); covered is updated in the same pass.
+__global__ __launch_bounds__(256) void k_newly_mask(u64 *__restrict__ covered, const u64 *__restrict__ cols, u64 wp,
+                                                    const Pending pend, const IterState *__restrict__ st, u64 *__restrict__ mask)
+{
+    if (st->done) return;
+    const u64 *wcol = pending_column(st, cols, wp, pend);
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) {
+        u64 x = 0;
+        if (wcol) {
+            const u64 c = covered[w];
+            x = __hip_atomic_load(&wcol[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) & ~c;
+            if (x) covered[w] = c | x;
+        }
+        mask[w] = x;
     }
 }
 

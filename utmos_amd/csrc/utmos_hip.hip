@@ -102,6 +102,7 @@ struct Chunk {
     int index = 0;
     const u64 **d_peer_cols = nullptr;  // device array [n_ranks]: this chunk's column base on every rank (P2P), or null
     std::vector<void *> ipc_opened;     // mappings to close
+    u64 *mask = nullptr;           // AF delta scoring: per word, the bits the last winner newly covered
     unsigned *list_idx = nullptr;  // decremental scoring: words newly covered by the last winner
     u64 *list_val = nullptr;
     std::vector<float> h_af32;
@@ -263,6 +264,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
         (void)hipFree(ch.af);
         (void)hipFree(ch.list_idx);
         (void)hipFree(ch.list_val);
+        (void)hipFree(ch.mask);
     }
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
@@ -606,6 +608,9 @@ static int build_af_tables(utm_ctx *c)
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     c->d_segs = nullptr;
     c->chain_fast = ChainFast{nullptr, 0, nullptr, nullptr};
+    if (c->af_fixed)
+        for (auto &ch : c->chunks)
+            if (!ch.mask) HIP_TRY(hipMalloc(&ch.mask, ch.wp * 8));
     if (c->af_fixed) {
         std::vector<ChainSeg> segs;
         for (size_t k = 0; k < c->chunks.size(); ++k)
@@ -720,12 +725,22 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     a.state = c->d_state;
     a.weights = c->have_weights ? c->d_weights : nullptr;
     const bool afs = c->af_mode != UTM_AF_NONE && c->af_fixed;
-    a.cnt = decr ? c->d_cnt_keep : c->d_cnt;
-    a.afsum = afs ? (decr ? c->d_afsum_keep : c->d_afsum) : nullptr;
-    // full iterations leave a copy of every count behind: the state decremental iterations continue from
-    a.cnt_mirror = (!decr && c->decr_enabled) ? c->d_cnt_keep : nullptr;
-    a.afsum_mirror = (!decr && c->decr_enabled && afs) ? c->d_afsum_keep : nullptr;
-    a.zero_after = decr ? 0 : 1;
+    if (afs) {
+        // AF (verified-parallel): the accumulators are persistent -- a full pass fills them once, later passes
+        // subtract what the last winner newly covered (streamed delta pass, or the gather form when that is tiny)
+        a.cnt = c->d_cnt;
+        a.afsum = c->d_afsum;
+        a.cnt_mirror = nullptr;
+        a.afsum_mirror = nullptr;
+        a.zero_after = 0;
+    } else {
+        a.cnt = decr ? c->d_cnt_keep : c->d_cnt;
+        a.afsum = nullptr;
+        // full iterations leave a copy of every count behind: the state decremental iterations continue from
+        a.cnt_mirror = (!decr && c->decr_enabled) ? c->d_cnt_keep : nullptr;
+        a.afsum_mirror = nullptr;
+        a.zero_after = decr ? 0 : 1;
+    }
     a.list_n = decr ? c->d_listn : nullptr;  // read for the accounting, then cleared, by k_pick
     a.n_chunks = (int)c->chunks.size();
     a.fscore = c->af_mode != UTM_AF_NONE ? c->d_fscore : nullptr;  // sequential scores (fallback / overflow)
@@ -831,7 +846,7 @@ static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
 // The streaming kernels (k_score_int, k_score_afs): grid = variant tiles x groups of samples.  Tile = the largest
 // of {32 (AF: 16), 8, 2} KiB that still yields >= UTM_MIN_WGS workgroups; group size such that the grid has about
 // UTM_TARGET_WGS workgroups (>> 256 CUs, small enough units for an even tail), at least one sample per wave.
-static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub)
+static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta = false)
 {
     static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
     static const int min_wgs = tune_env("UTM_MIN_WGS", 1024);
@@ -858,7 +873,8 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub)
         const int eb = 150 - c->af_q;
 #define UTM_LAUNCH_AFS(S, Q)                                                                                              \
     hipLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb,   \
-                       pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups)
+                       pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups,        \
+                       delta ? ch.mask : nullptr)
         if (steps == 32) UTM_LAUNCH_AFS(32, 8);  // second argument: queue depth per lane
         else if (steps == 16) UTM_LAUNCH_AFS(16, 16);
         else if (steps == 8) UTM_LAUNCH_AFS(8, 16);
@@ -875,17 +891,33 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
     const unsigned a_ub = std::max(1u, c->active_ub);
     if (c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential)) {
         launch_score_sequential(c, a_ub);
-    } else {
-        // AF: dense phase -> LDS-tile kernel, afterwards the streaming kernel.  The captured fraction is known from
-        // the last batch sync (identical on every shard).
-        const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
-        const double af_switch = sw && *sw ? atof(sw) : 0.2;
-        const bool af_dense = c->af_mode != UTM_AF_NONE && (double)c->captured_seen < af_switch * (double)c->n_var_total;
-        if (c->p2p) launch_apply_pending(c);  // the scoring kernels do not fuse the update here: read the winner's column once
-        for (auto &ch : c->chunks) {
-            if (af_dense) launch_score_af_dense(c, ch, a_ub);
-            else launch_score_streaming(c, ch, a_ub);
+    } else if (c->af_mode != UTM_AF_NONE) {
+        // AF, verified-parallel: persistent accumulators.  Without valid accumulators: clear them and run a full
+        // pass (dense phase -> LDS-tile kernel, else the streaming kernel).  Otherwise a *delta* pass: the mask of
+        // variants the last winner newly covered is made once (k_newly_mask, which also updates covered, from a
+        // local or a peer-mapped column) and the streaming kernel subtracts those variants' share -- same bytes
+        // streamed, but only the newly covered bits take the queue / gather path.
+        if (!c->keep_valid) {
+            HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
+            const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
+            const double af_switch = sw && *sw ? atof(sw) : 0.2;
+            const bool af_dense = (double)c->captured_seen < af_switch * (double)c->n_var_total;
+            if (c->p2p) launch_apply_pending(c);
+            for (auto &ch : c->chunks) {
+                if (af_dense) launch_score_af_dense(c, ch, a_ub);
+                else launch_score_streaming(c, ch, a_ub);
+            }
+            c->keep_valid = true;
+        } else {
+            for (auto &ch : c->chunks)
+                hipLaunchKernelGGL(k_newly_mask, dim3((unsigned)std::min<u64>(2048, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                                   ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, ch.mask);
+            for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub, /*delta=*/true);
         }
+    } else {
+        if (c->p2p) launch_apply_pending(c);  // the scoring kernels do not fuse the update here: read the winner's column once
+        for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub);
     }
     HIP_TRY(hipGetLastError());
     return UTM_OK;
@@ -905,7 +937,7 @@ static int enqueue_score_decr(utm_ctx *c)
         const dim3 grid((a_ub + 3) / 4, split);
         if (af)
             hipLaunchKernelGGL(k_decr<true>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, reinterpret_cast<const unsigned *>(ch.af32),
-                               150 - c->af_q, c->d_st, c->d_act, ch.list_idx, ch.list_val, c->d_listn + k, c->d_cnt_keep, c->d_afsum_keep);
+                               150 - c->af_q, c->d_st, c->d_act, ch.list_idx, ch.list_val, c->d_listn + k, c->d_cnt, c->d_afsum);
         else
             hipLaunchKernelGGL(k_decr<false>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, (const unsigned *)nullptr, 0, c->d_st,
                                c->d_act, ch.list_idx, ch.list_val, c->d_listn + k, c->d_cnt_keep, c->d_afsum_keep);
@@ -1054,7 +1086,8 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         }
         c->decr_entries_seen = c->h_st->decr_entries;
         c->decr_gathers_seen = c->h_st->decr_gathers;
-        c->keep_valid = c->decr_enabled;  // a full pass mirrored the counts; a decremental one kept them current
+        // a full pass mirrored the counts (integer mode with the decremental option) / the AF accumulators are persistent
+        c->keep_valid = c->decr_enabled || (c->af_mode != UTM_AF_NONE && c->af_fixed);
         if (rows > 0) HIP_TRY(copy_sync(c, &c->last_new, c->d_res_new + c->iter - 1, 8, hipMemcpyDeviceToHost));
         c->scored += passes;
         if (c->flags & UTM_FLAG_PROFILE_EVENTS) TRY(collect_event_times(c));
