@@ -861,7 +861,7 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
         const u64 tiles = (steps_total + cand - 1) / cand;
         if (tiles * waves_needed >= (u64)min_wgs) { steps = cand; break; }
     }
-    if (!af && (force_steps == 32 || force_steps == 8 || force_steps == 2)) steps = force_steps;
+    if (!af && (force_steps == 32 || force_steps == 16 || force_steps == 8 || force_steps == 2)) steps = force_steps;
     const u64 tiles = (steps_total + steps - 1) / steps;
     u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
     group = std::max<u64>(4, (group + 3) / 4 * 4);
@@ -881,6 +881,7 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
         else UTM_LAUNCH_AFS(2, 16);
 #undef UTM_LAUNCH_AFS
     } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else if (steps == 16) launch_score_int<16>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
     else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
     else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
 }
