@@ -553,8 +553,9 @@ def test_randomised_configurations_against_the_oracle(dev):
     import os
     rng = np.random.default_rng(int(os.environ.get("UTM_FUZZ_SEED", "2026")))
     for trial in range(int(os.environ.get("UTM_FUZZ_TRIALS", "70"))):
-        n_var = int(rng.choice([1, 5, 63, 64, 65, 127, 500, 1500, 4000, 9000]))
-        n_samp = int(rng.choice([1, 2, 3, 7, 33, 64, 65, 130, 257]))
+        big = os.environ.get("UTM_FUZZ_BIG") == "1"      # occasional campaign with multi-tile shapes
+        n_var = int(rng.choice([20000, 70000, 150000, 300000] if big else [1, 5, 63, 64, 65, 127, 500, 1500, 4000, 9000]))
+        n_samp = int(rng.choice([40, 130, 300] if big else [1, 2, 3, 7, 33, 64, 65, 130, 257]))
         density = float(rng.choice([0.01, 0.05, 0.3, 0.7]))
         dense = rng.random((n_var, n_samp)) < density
         if rng.random() < 0.7:
