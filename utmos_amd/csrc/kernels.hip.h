@@ -705,6 +705,20 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
 // The reference's chain for ONE candidate per workgroup: 1024 lanes compact the AF values of the
 // candidate's surviving bits, in ascending variant order, into LDS (popcount -> block prefix sum ->
 // scatter); lane 0 then adds them one by one in float64.  Only the additions are serial.
+// Strictly ordered float64 sum of the 64 values a wave holds (lane i = i-th addend): every lane reads the addends
+// one after the other with v_readlane (no memory in the dependent chain) and all lanes keep the same running sum.
+// Lanes past the end of a list must hold +0.0, which leaves the sum unchanged bit for bit.
+__device__ __forceinline__ double ordered_sum64(double acc, double v)
+{
+    const int lo = (int)(__builtin_bit_cast(u64, v) & 0xFFFFFFFFu), hi = (int)(__builtin_bit_cast(u64, v) >> 32);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const u64 bits = ((u64)(unsigned)__builtin_amdgcn_readlane(hi, i) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, i);
+        acc += __builtin_bit_cast(double, bits);
+    }
+    return acc;
+}
+
 // Fast path of the chains (sparse candidates, i.e. almost every iteration after the first few): the
 // candidate's column is cut into segments of 4096 words; k_chain_fill lets one workgroup per
 // (segment, candidate) compact the AF values of the surviving bits, in order, into a global buffer;
@@ -791,22 +805,15 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
             if (cnts[g] == 0xFFFFFFFFu) dense = 1;
         __syncthreads();
         if (!dense) {
-            if (tid == 0) {
+            if (wave == 0) {  // one wave: coalesced loads of 64 values, then the ordered sum in registers
                 double acc = 0.0;
                 const double *vals = f.vals + (size_t)blockIdx.x * f.n_segs * UTM_SEG_CAP;
                 for (int g = 0; g < f.n_segs; ++g) {
                     const unsigned m = cnts[g];
                     const double *v = vals + (size_t)g * UTM_SEG_CAP;
-                    unsigned t = 0;
-                    for (; t + 8 <= m; t += 8) {
-                        const double v0 = v[t], v1 = v[t + 1], v2 = v[t + 2], v3 = v[t + 3];
-                        const double v4 = v[t + 4], v5 = v[t + 5], v6 = v[t + 6], v7 = v[t + 7];
-                        acc += v0; acc += v1; acc += v2; acc += v3;
-                        acc += v4; acc += v5; acc += v6; acc += v7;
-                    }
-                    for (; t < m; ++t) acc += v[t];
+                    for (unsigned t = 0; t < m; t += 64) acc = ordered_sum64(acc, t + lane < m ? v[t + lane] : 0.0);
                 }
-                cand->val[blockIdx.x] = acc;
+                if (lane == 0) cand->val[blockIdx.x] = acc;
             }
             return;
         }
@@ -860,16 +867,9 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
                     }
                 }
                 __syncthreads();
-                if (tid == 0) {
+                if (wave == 0) {
                     const unsigned m = total - base < UTM_CHAIN_CAP ? total - base : UTM_CHAIN_CAP;
-                    unsigned t = 0;
-                    for (; t + 8 <= m; t += 8) {  // loads up front, then the strictly ordered additions
-                        const double v0 = buf[t], v1 = buf[t + 1], v2 = buf[t + 2], v3 = buf[t + 3];
-                        const double v4 = buf[t + 4], v5 = buf[t + 5], v6 = buf[t + 6], v7 = buf[t + 7];
-                        acc += v0; acc += v1; acc += v2; acc += v3;
-                        acc += v4; acc += v5; acc += v6; acc += v7;
-                    }
-                    for (; t < m; ++t) acc += buf[t];
+                    for (unsigned t = 0; t < m; t += 64) acc = ordered_sum64(acc, t + lane < m ? buf[t + lane] : 0.0);
                 }
                 __syncthreads();
             }
