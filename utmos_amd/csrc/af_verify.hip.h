@@ -1,0 +1,268 @@
+// Verification of the parallel AF sums: intervals, candidates, the reference's sequential chains.
+#pragma once
+#include "score_af.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// Verified-parallel AF scoring.  The reference's AF score of a sample is a float64 running sum in
+// ascending variant order (select.py:40); float64 addition does not reassociate, so a parallel sum is
+// only an *estimate* E with a rigorous bound B on |reference - E|:
+//   float32 AF: E = exact integer sum of AF*2^q.  While E < 2^53 every partial sum of the reference
+//               is exact, hence reference == E (B = 0).  Beyond: B = n * 2^-53 * E (n addends).
+//   float64 AF: E sums the float32-rounded values exactly: B = (2^-24 + n * 2^-53) * E.
+// k_cand keeps the samples whose weighted interval reaches the best lower bound -- only they can be
+// the argmax -- and k_chain recomputes exactly those few with the reference's sequential chain.
+// Result: bit-identical winner and score, with the bulk of the work order independent.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c, double &lo, double &hi, double &est,
+                                            bool &exact)
+{
+    const i64 e = a.afsum[s];
+    est = (double)e * a.af_scale;
+    double bound;
+    if (a.af_is_f64) {
+        exact = c == 0;
+        bound = exact ? 0.0 : 1.02 * (5.9604644775390625e-08 + (double)c * 1.1102230246251565e-16) * est;
+    } else {
+        exact = e < (1ll << 53);
+        bound = exact ? 0.0 : 1.05 * ((double)c * 1.1102230246251565e-16 * est + 1.2e-16 * est);
+    }
+    double l = est - bound, h = est + bound;
+    if (l < 0.0) l = 0.0;
+    if (a.weights) {
+        const double w = a.weights[a.first + s];
+        l *= w;  // rounding is monotone: fl(R*w) lies between fl(l*w) and fl(h*w)
+        h *= w;
+        if (w < 0.0) { const double t = l; l = h; h = t; }
+    }
+    lo = l;
+    hi = h;
+}
+
+__global__ __launch_bounds__(256) void k_cand(PickArgs a)
+{
+    __shared__ double wmax[4];
+    __shared__ unsigned n_c;
+    __shared__ int inexact, any_inexact;
+    IterState *st = a.st;
+    if (st->done) return;
+    const unsigned n_active = st->n_active;
+    if (threadIdx.x == 0) { n_c = 0; inexact = 0; any_inexact = 0; }
+    double best_lo = -__builtin_inf();
+    for (unsigned i = threadIdx.x; i < n_active; i += 256) {
+        const unsigned s = a.act[i];
+        double lo, hi, est;
+        bool exact;
+        af_interval(a, s, a.cnt[s], lo, hi, est, exact);
+        best_lo = lo > best_lo ? lo : best_lo;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(best_lo, o, 64);
+        best_lo = other > best_lo ? other : best_lo;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best_lo;
+    __syncthreads();
+    best_lo = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    for (unsigned i = threadIdx.x; i < n_active; i += 256) {
+        const unsigned s = a.act[i];
+        const u64 c = a.cnt[s];
+        double lo, hi, est;
+        bool exact;
+        af_interval(a, s, c, lo, hi, est, exact);
+        if (!exact) any_inexact = 1;
+        if (hi >= best_lo) {
+            const unsigned slot = atomicAdd(&n_c, 1u);
+            if (slot < UTM_MAX_CAND) {
+                a.cand->pos[slot] = i;
+                a.cand->samp[slot] = s;
+                a.cand->cnt[slot] = (i64)c;
+                a.cand->val[slot] = est;
+            }
+            if (!exact) inexact = 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        st->n_cand = n_c < UTM_MAX_CAND ? (int)n_c : UTM_MAX_CAND;
+        st->cand_overflow = n_c > UTM_MAX_CAND;
+        st->need_chain = inexact;
+        st->all_exact = !any_inexact;
+    }
+}
+
+
+// The reference's chain for ONE candidate per workgroup: 1024 lanes compact the AF values of the
+// candidate's surviving bits, in ascending variant order, into LDS (popcount -> block prefix sum ->
+// scatter); lane 0 then adds them one by one in float64.  Only the additions are serial.
+// Strictly ordered float64 sum of the 64 values a wave holds (lane i = i-th addend): every lane reads the addends
+// one after the other with v_readlane (no memory in the dependent chain) and all lanes keep the same running sum.
+// Lanes past the end of a list must hold +0.0, which leaves the sum unchanged bit for bit.
+__device__ __forceinline__ double ordered_sum64(double acc, double v)
+{
+    const int lo = (int)(__builtin_bit_cast(u64, v) & 0xFFFFFFFFu), hi = (int)(__builtin_bit_cast(u64, v) >> 32);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const u64 bits = ((u64)(unsigned)__builtin_amdgcn_readlane(hi, i) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, i);
+        acc += __builtin_bit_cast(double, bits);
+    }
+    return acc;
+}
+
+// Fast path of the chains (sparse candidates, i.e. almost every iteration after the first few): the
+// candidate's column is cut into segments of 4096 words; k_chain_fill lets one workgroup per
+// (segment, candidate) compact the AF values of the surviving bits, in order, into a global buffer;
+// k_chain's wave 0 then only walks the per-segment counts and adds the values in order.  A segment
+// with more than UTM_SEG_CAP values, or more than UTM_FAST_CAND candidates, leaves the candidate to
+// the one-workgroup chain below.
+#define UTM_FAST_CAND 8
+#define UTM_SEG_CAP 1024
+#define UTM_SEG_WORDS 4096
+struct ChainSeg {
+    int chunk;
+    u64 w0;
+};
+struct ChainFast {
+    const ChainSeg *segs;
+    int n_segs;
+    unsigned *counts;  // [UTM_FAST_CAND][n_segs]; 0xFFFFFFFF = segment too dense
+    double *vals;      // [UTM_FAST_CAND][n_segs][UTM_SEG_CAP]
+};
+
+template <typename AF_T>
+__global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict__ chunks, const IterState *__restrict__ st,
+                                                     const CandBuf *__restrict__ cand, ChainFast f)
+{
+    __shared__ unsigned wtot[16];
+    if (st->done || !st->need_chain || st->cand_overflow || st->n_cand > UTM_FAST_CAND || (int)blockIdx.y >= st->n_cand) return;
+    const ChainSeg sg = f.segs[blockIdx.x];
+    const SeqChunk ch = chunks[sg.chunk];
+    const unsigned s = cand->samp[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 *col = ch.cols + (u64)s * ch.wp;
+    const AF_T *af = static_cast<const AF_T *>(ch.af);
+    const u64 w = sg.w0 + (u64)tid * 4;
+    u64 x[4];
+    unsigned n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        x[k] = w + k < ch.w ? (col[w + k] & ~ch.covered[w + k]) : 0;
+        n += __popcll(x[k]);
+    }
+    const unsigned incl = wave_scan_incl_u32(n);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned woff = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const unsigned t = wtot[k];
+        woff += k < wave ? t : 0;
+        total += t;
+    }
+    const size_t slot = (size_t)blockIdx.y * f.n_segs + blockIdx.x;
+    if (tid == 0) f.counts[slot] = total <= UTM_SEG_CAP ? total : 0xFFFFFFFFu;
+    if (total == 0 || total > UTM_SEG_CAP) return;
+    double *out = f.vals + slot * UTM_SEG_CAP + (woff + incl - n);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u64 y = x[k];
+        while (y) {
+            const int b = __builtin_ctzll(y);
+            y &= y - 1;
+            *out++ = (double)af[(w + k) * 64 + b];
+        }
+    }
+}
+
+#define UTM_CHAIN_CAP 2048
+#define UTM_CHAIN_WPT 4  // consecutive words per lane and round: 4096 words (262,144 variants) per round
+template <typename AF_T>
+__global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chunks, int n_chunks,
+                                                const IterState *__restrict__ st, CandBuf *__restrict__ cand, ChainFast f)
+{
+    __shared__ double buf[UTM_CHAIN_CAP];
+    __shared__ unsigned wtot[2][16];  // double buffered: one barrier per empty round
+    __shared__ int dense;
+    if (st->done || !st->need_chain || st->cand_overflow || (int)blockIdx.x >= st->n_cand) return;
+    const unsigned s = cand->samp[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (f.counts && st->n_cand <= UTM_FAST_CAND) {
+        // fast path: k_chain_fill compacted this candidate's values per segment; are all segments usable?
+        const unsigned *cnts = f.counts + (size_t)blockIdx.x * f.n_segs;
+        if (tid == 0) dense = 0;
+        __syncthreads();
+        for (int g = tid; g < f.n_segs; g += 1024)
+            if (cnts[g] == 0xFFFFFFFFu) dense = 1;
+        __syncthreads();
+        if (!dense) {
+            if (wave == 0) {  // one wave: coalesced loads of 64 values, then the ordered sum in registers
+                double acc = 0.0;
+                const double *vals = f.vals + (size_t)blockIdx.x * f.n_segs * UTM_SEG_CAP;
+                for (int g = 0; g < f.n_segs; ++g) {
+                    const unsigned m = cnts[g];
+                    const double *v = vals + (size_t)g * UTM_SEG_CAP;
+                    for (unsigned t = 0; t < m; t += 64) acc = ordered_sum64(acc, t + lane < m ? v[t + lane] : 0.0);
+                }
+                if (lane == 0) cand->val[blockIdx.x] = acc;
+            }
+            return;
+        }
+    }
+    double acc = 0.0;
+    unsigned round = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const SeqChunk ch = chunks[c];
+        const u64 *col = ch.cols + (u64)s * ch.wp;
+        const AF_T *af = static_cast<const AF_T *>(ch.af);
+        // wp is a multiple of 128 words, so whole groups of UTM_CHAIN_WPT words never straddle its end
+        auto fetch = [&](u64 w, u64 *x) {
+#pragma unroll
+            for (int k = 0; k < UTM_CHAIN_WPT; ++k) x[k] = w + k < ch.w ? (col[w + k] & ~ch.covered[w + k]) : 0;
+        };
+        u64 x_next[UTM_CHAIN_WPT];
+        fetch((u64)tid * UTM_CHAIN_WPT, x_next);
+        for (u64 w0 = 0; w0 < ch.w; w0 += 1024 * UTM_CHAIN_WPT, ++round) {
+            const u64 w = w0 + (u64)tid * UTM_CHAIN_WPT;
+            u64 x[UTM_CHAIN_WPT];
+            unsigned n = 0;
+#pragma unroll
+            for (int k = 0; k < UTM_CHAIN_WPT; ++k) {
+                x[k] = x_next[k];
+                n += __popcll(x[k]);
+            }
+            fetch(w + 1024 * UTM_CHAIN_WPT, x_next);  // in flight during this round
+            const unsigned incl = wave_scan_incl_u32(n);
+            unsigned *wt = wtot[round & 1];
+            if (lane == 63) wt[wave] = incl;
+            __syncthreads();
+            unsigned woff = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const unsigned t = wt[k];
+                woff += k < wave ? t : 0;
+                total += t;
+            }
+            if (total == 0) continue;  // the other wtot buffer is written next round
+            const unsigned off = woff + incl - n;
+            for (unsigned base = 0; base < total; base += UTM_CHAIN_CAP) {
+                unsigned p = off;
+#pragma unroll
+                for (int k = 0; k < UTM_CHAIN_WPT; ++k) {
+                    u64 y = x[k];
+                    while (y) {
+                        const int b = __builtin_ctzll(y);
+                        y &= y - 1;
+                        if (p >= base && p < base + UTM_CHAIN_CAP) buf[p - base] = (double)af[(w + k) * 64 + b];
+                        ++p;
+                    }
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const unsigned m = total - base < UTM_CHAIN_CAP ? total - base : UTM_CHAIN_CAP;
+                    for (unsigned t = 0; t < m; t += 64) acc = ordered_sum64(acc, t + lane < m ? buf[t + lane] : 0.0);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (tid == 0) cand->val[blockIdx.x] = acc;
+}

@@ -1,0 +1,22 @@
+// Covered-mask maintenance outside the scoring kernels.
+#pragma once
+#include "common.hip.h"
+
+// covered |= pending winner column (used where the update is not fused into a scoring kernel)
+__global__ __launch_bounds__(256) void k_apply_pending(u64 *__restrict__ covered, const u64 *__restrict__ cols, u64 wp,
+                                                       const Pending pend,
+                                                       const IterState *__restrict__ st)
+{
+    const u64 *wcol = pending_column(st, cols, wp, pend);
+    if (!wcol) return;
+    // the column may live in another process / on another GPU (hipIpc mapping): system-scope loads, so that
+    // no cache of this GPU can answer with an older copy of those addresses
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256)
+        covered[w] |= __hip_atomic_load(&wcol[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// covered |= cols[col]  (utm_reset: samples that start out "used")
+__global__ __launch_bounds__(256) void k_or_column(u64 *__restrict__ covered, const u64 *__restrict__ col, u64 wp)
+{
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) covered[w] |= col[w];
+}

@@ -1,0 +1,92 @@
+// Ingest and set-up kernels: bit transpose of the reference's row packing, AF == 0 rows, var_count, synthetic generator.
+#pragma once
+#include "common.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// Ingest helpers
+// ------------------------------------------------------------------------------------------------
+// Bit transpose of the reference's packing (rows = variants, MSB-first bits along samples,
+// convert.py:85) into columns.  One wave = 64 variants x 64 samples: lane l holds the 64 sample bits
+// of variant v0+l; 64 ballots turn them into 64 column words; lane j stores sample j's word.
+__global__ __launch_bounds__(64) void k_transpose_rows(const unsigned char *__restrict__ rows, u64 row_stride,
+                                                       u64 n_rows, u64 first_word, u64 *__restrict__ cols, u64 wp,
+                                                       unsigned first_sample, unsigned n_local, unsigned n_total)
+{
+    const u64 vw = blockIdx.x;     // word (64 variants) inside this upload
+    const unsigned sb = blockIdx.y;  // block of 64 local samples
+    const int lane = threadIdx.x;
+    const u64 v = vw * 64 + lane;
+    const unsigned sg0 = first_sample + sb * 64;  // first global sample of the block
+    u64 window = 0;  // bit (63 - j) = sample sg0 + j
+    if (v < n_rows) {
+        const unsigned char *row = rows + v * row_stride;
+        const unsigned byte0 = sg0 >> 3, sh = sg0 & 7;
+        const unsigned n_bytes = (n_total + 7) >> 3;
+        u64 hi = 0;
+        for (int b = 0; b < 8; ++b) hi = (hi << 8) | (byte0 + b < n_bytes ? row[byte0 + b] : 0);
+        const unsigned nxt = byte0 + 8 < n_bytes ? row[byte0 + 8] : 0;
+        window = sh ? (hi << sh) | (nxt >> (8 - sh)) : hi;
+    }
+    u64 mine = 0;
+    for (int j = 0; j < 64; ++j) {
+        const u64 word = __ballot((window >> (63 - j)) & 1);
+        if (lane == j) mine = word;
+    }
+    const unsigned s_local = sb * 64 + lane;
+    if (s_local < n_local && sg0 + lane < n_total) cols[(u64)s_local * wp + first_word + vw] = mine;
+}
+
+// cols[s][w] &= keep[w]   (variants whose AF is exactly 0 are all-zero rows in the reference's matrix)
+__global__ __launch_bounds__(256) void k_mask_rows(u64 *__restrict__ cols, u64 wp, const u64 *__restrict__ keep, u64 w_words,
+                                                   unsigned n_local)
+{
+    const u64 total = (u64)n_local * w_words;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < total; i += (u64)gridDim.x * 256) {
+        const u64 s = i / w_words, w = i % w_words;
+        cols[s * wp + w] &= keep[w];
+    }
+}
+
+// var_count: out[s] += popcount(column s)
+__global__ __launch_bounds__(256) void k_col_popcount(const u64 *__restrict__ cols, u64 wp, u64 *__restrict__ out)
+{
+    const unsigned s = blockIdx.x;
+    const u64 *col = cols + (u64)s * wp;
+    unsigned acc = 0;
+    u64 total = 0;
+    for (u64 w = threadIdx.x; w < wp; w += 256) {
+        acc += __popcll(col[w]);
+        if (acc > 0xF0000000u) { total += acc; acc = 0; }
+    }
+    total += acc;
+    __shared__ u64 part[4];
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) out[s] += part[0] + part[1] + part[2] + part[3];
+}
+
+// Synthetic chunk contents: thread = one word (64 variants) of one local sample.  Grid = (word blocks,
+// min(samples, 65535)); the samples are strided over grid.y -- a 1-D grid of words x samples would exceed
+// HIP's 2^32 threads per grid dimension on large chunks and be silently truncated.
+__global__ __launch_bounds__(256) void k_synth(u64 *__restrict__ cols, u64 wp, u64 n_var, u64 first_var_global,
+                                               u64 seed, unsigned n_total, unsigned first_sample, unsigned octaves,
+                                               u64 words_per_col, unsigned n_local)
+{
+    const u64 w = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (w >= words_per_col) return;
+    for (unsigned s = blockIdx.y; s < n_local; s += gridDim.y) {
+        const unsigned sg = first_sample + s;
+        const u64 skey = utm_sample_key(sg);
+        u64 word = 0;
+        for (int b = 0; b < 64; ++b) {
+            const u64 v = w * 64 + b;
+            if (v >= n_var) break;
+            const u64 key = utm_var_key(seed, first_var_global + v);
+            const unsigned thr = utm_var_threshold(key, octaves);
+            const unsigned forced = utm_var_forced(key, n_total);
+            word |= (u64)utm_cell(key, thr, forced, skey, sg) << b;
+        }
+        cols[(u64)s * wp + w] = word;
+    }
+}

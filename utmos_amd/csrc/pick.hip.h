@@ -1,0 +1,238 @@
+// K2: mask / weight / argmax, the decision of an iteration, and the exchange between shards.
+#pragma once
+#include "common.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// K2: mask / weight / argmax (select.py:43-53) over the selectable local samples and, when this is
+// the only shard, the decision and bookkeeping of greedy_select (select.py:93-112).  One workgroup.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool better(const Cand &a, const Cand &b)
+{  // np.argmax: highest score, first (lowest) index on ties
+    return a.val > b.val || (a.val == b.val && a.gidx < b.gidx);
+}
+__device__ __forceinline__ Cand shfl_cand(const Cand &c, int o)
+{
+    Cand r;
+    r.val = __shfl_xor(c.val, o, 64);
+    r.gidx = __shfl_xor(c.gidx, o, 64);
+    r.cnt = __shfl_xor(c.cnt, o, 64);
+    r.pos = __shfl_xor(c.pos, o, 64);
+    return r;
+}
+
+
+
+// Runs in ONE thread.  Same inputs on every shard => same decision on every shard.
+__device__ void decide(const PickArgs &a)
+{
+    IterState *st = a.st;
+    Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+    int best_rank = -1;
+    for (int r = 0; r < a.n_ranks; ++r) {
+        const Rec *rc = rec_of(a, r);
+        if (rc->idx < 0) continue;
+        Cand c{rc->score, rc->idx, rc->new_count, 0};
+        if (best_rank < 0 || better(c, best)) { best = c; best_rank = r; }
+    }
+    const i64 k = st->iter;
+    // argmax runs over ALL samples in the reference; non-selectable ones hold 0 (select.py:43), so a
+    // negative best only wins when no such sample exists.
+    const bool zero_elsewhere = st->n_active_total < (i64)a.n_total;
+    if (best_rank < 0 || best.val == 0.0 || (best.val < 0.0 && zero_elsewhere)) {
+        st->done = 1;  // (None, None): no row for this iteration (select.py:51-52, :93-96)
+        a.res_idx[k] = -1;
+        return;
+    }
+    a.res_idx[k] = best.gidx;
+    a.res_new[k] = best.cnt;
+    a.res_score[k] = best.val;
+    st->iter = k + 1;
+    st->tot += best.cnt;
+    st->n_active_total -= 1;
+    st->prev_valid = 1;
+    st->prev_rank = best_rank;
+    st->prev_gidx = best.gidx;
+    if (best.gidx >= (i64)a.first && best.gidx < (i64)a.first + a.n_local) {
+        const unsigned loc = (unsigned)(best.gidx - a.first);
+        a.state[loc] = 0;  // sample_mask[use_sample] = 0 (select.py:100)
+        const unsigned n = st->n_active;
+        a.act[st->best_pos] = a.act[n - 1];
+        st->n_active = n - 1;
+        st->prev_local = (int)loc;
+    } else {
+        st->prev_local = -1;
+    }
+    if (st->tot >= a.n_var_total) st->done = 1;  // "Ran out of new variants" (select.py:110-112)
+}
+
+// Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
+// landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
+#define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
+__device__ __forceinline__ bool mbox_wait(const Mailbox *slot, u64 expected, Rec *out)
+{
+    for (unsigned spin = 0; spin < UTM_MBOX_SPINS; ++spin) {
+        if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == expected) {
+            out->score = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&slot->score), __ATOMIC_RELAXED,
+                                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+            out->idx = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            out->new_count = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->new_count), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_SYSTEM);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return false;
+}
+
+// MODE 0: single shard -- pick and decide.  1: write this shard's record into its exchange slot.
+// 2: as 1, and post the record into every shard's mailbox (device-side exchange over P2P mappings).
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_pick(PickArgs a)
+{
+    __shared__ Cand wbest[16];
+    __shared__ Rec srec;
+    __shared__ int late;
+    IterState *st = a.st;
+    if (st->done) return;
+    const unsigned n_active = st->n_active;
+    // where this iteration's scores come from
+    //   0 integer counts | 1 exact fixed-point AF sums | 2 sequential float64 scores of every sample
+    //   3 the candidates' sequential float64 scores (k_chain)
+    int src = a.afsum ? 1 : a.fscore ? 2 : 0;
+    if (a.cand && st->need_chain) src = st->cand_overflow ? 2 : 3;
+    Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+    if (src == 3) {
+        const unsigned n_cand = (unsigned)st->n_cand;
+        for (unsigned b = threadIdx.x; b < n_cand; b += 1024) {
+            const unsigned s = a.cand->samp[b];
+            double v = a.cand->val[b];
+            if (a.weights) v *= a.weights[a.first + s];
+            const Cand cand{v, (i64)a.first + s, a.cand->cnt[b], a.cand->pos[b]};
+            if (better(cand, best)) best = cand;
+        }
+    }
+    for (unsigned i = threadIdx.x; i < n_active; i += 1024) {
+        const unsigned s = a.act[i];
+        const u64 c = a.cnt[s];
+        if (a.zero_after) a.cnt[s] = 0;  // ready for the next iteration's atomics
+        if (a.cnt_mirror) a.cnt_mirror[s] = c;
+        double v = (double)c;
+        if (a.afsum) {
+            const i64 q = a.afsum[s];
+            if (a.zero_after) a.afsum[s] = 0;
+            if (a.afsum_mirror) a.afsum_mirror[s] = q;
+            v = (double)q * a.af_scale;  // exact: q < 2^53 whenever this value is used, and the scale is a power of two
+        }
+        if (src == 3) continue;
+        if (src == 2) v = a.fscore[s];
+        if (a.weights) v *= a.weights[a.first + s];
+        const Cand cand{v, (i64)a.first + s, (i64)c, i};
+        if (better(cand, best)) best = cand;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const Cand other = shfl_cand(best, o);
+        if (better(other, best)) best = other;
+    }
+    if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (better(wbest[w], best)) best = wbest[w];
+        Rec *rc = rec_of(a, a.rank);
+        rc->score = n_active ? best.val : 0.0;
+        rc->idx = n_active ? best.gidx : -1;
+        rc->new_count = n_active ? best.cnt : 0;
+        st->best_pos = best.pos;
+        if (MODE == 2) {
+            late = 0;
+            srec.score = rc->score;
+            srec.idx = rc->idx;
+            srec.new_count = rc->new_count;
+        }
+        if (a.list_n) {
+            u64 n_l = 0;
+            for (int c = 0; c < a.n_chunks; ++c) {
+                n_l += a.list_n[c];
+                a.list_n[c] = 0;
+            }
+            st->decr_entries += n_l;
+            st->decr_gathers += n_l * n_active;
+        }
+        if (MODE == 0) decide(a);
+    }
+    if (MODE == 2) {
+        __syncthreads();
+        if ((int)threadIdx.x < a.n_ranks) {
+            // one lane per destination shard; payload first, sequence number last (release, system scope)
+            const u64 seq = st->xseq + 1;
+            Mailbox *dst = a.peer_mbox[threadIdx.x] + (seq & 1) * a.n_ranks + a.rank;
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->score), __builtin_bit_cast(u64, srec.score), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->idx), (u64)srec.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->new_count), (u64)srec.new_count, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // ... and collect that shard's record of the same exchange from the local mailbox
+            const Mailbox *slot = a.mbox + (seq & 1) * a.n_ranks + threadIdx.x;
+            if (!mbox_wait(slot, seq, rec_of(a, threadIdx.x))) late = 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (late) {
+                st->xerror = 1;  // a shard went away: end the loop, the host reports it
+                st->done = 1;
+            } else {
+                st->xseq += 1;
+                decide(a);
+            }
+        }
+    }
+}
+
+__global__ void k_decide(PickArgs a)
+{
+    if (a.st->done) return;
+    if (threadIdx.x == 0) decide(a);
+}
+
+// Mailbox self-test (utm_p2p_selftest): one full post + wait round with a recognisable payload.
+__global__ __launch_bounds__(64) void k_mbox_ping(Mailbox *mbox, Mailbox *const *peer_mbox, int rank, int n_ranks, u64 seq, int *ok)
+{
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < n_ranks) {
+        Mailbox *dst = peer_mbox[threadIdx.x] + (seq & 1) * n_ranks + rank;
+        __hip_atomic_store(reinterpret_cast<u64 *>(&dst->idx), (u64)(1000 * seq + rank), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        Rec got;
+        const Mailbox *slot = mbox + (seq & 1) * n_ranks + threadIdx.x;
+        if (!mbox_wait(slot, seq, &got) || got.idx != (i64)(1000 * seq + threadIdx.x)) bad = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && bad) *ok = 0;
+}
+
+// Exchange payload: this shard's best column (all chunks back to back) behind its record.
+__global__ __launch_bounds__(256) void k_pack(u64 *__restrict__ slot_body, const u64 *__restrict__ cols, u64 wp,
+                                              const IterState *__restrict__ st, const unsigned *__restrict__ act)
+{
+    if (st->done || st->n_active == 0) return;
+    const u64 *col = cols + (u64)act[st->best_pos] * wp;
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) slot_body[w] = col[w];
+}
+
+// Final per-sample scores of the pending iteration (utm_peek_scores): mask, scale, weight.
+__global__ __launch_bounds__(256) void k_final_scores(PickArgs a, i64 *__restrict__ counts_out, double *__restrict__ scores_out)
+{
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_local) return;
+    const bool usable = a.state[s] == 1;
+    const u64 c = usable ? a.cnt[s] : 0;
+    double v = 0.0;
+    if (usable) v = a.afsum ? (double)a.afsum[s] * a.af_scale : a.fscore ? a.fscore[s] : (double)c;
+    if (a.weights) v *= a.weights[a.first + s];
+    counts_out[s] = (i64)c;
+    scores_out[s] = v;
+}

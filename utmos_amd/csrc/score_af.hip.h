@@ -1,0 +1,257 @@
+// K1, allele-frequency weighted scores: dense LDS-tile kernel, streaming kernel (full and delta passes), sequential chain.
+#pragma once
+#include "score_int.hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// K1-AF (float32 AF as exact fixed point): besides the count, afsum[s] += the
+// sum of AF[v] * 2^q as int64 over the set, uncovered bits.  Tile = 8192 variants = one KiB of every
+// column: the float32 AF tile (32 KiB) and ~covered (1 KiB) sit in LDS; a wave keeps 4 samples' KiB
+// in flight, skips samples whose KiB has no surviving bit (the common case once coverage has grown),
+// otherwise walks the bits (ctz / clear-lowest / ds_read_b32 gather / mantissa << exponent / 64-bit add).
+// A float32 a = m * 2^(e-150) (m = 24-bit mantissa with the hidden bit, e = biased exponent), so
+// a * 2^q = m << (e - e_base), e_base = 150 - q >= the smallest exponent present (host checks).
+// ------------------------------------------------------------------------------------------------
+#define UTM_AF_TILE_WORDS 128
+__global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+                                                   const float *__restrict__ af, int e_base,
+                                                   const Pending pend,
+                                                   const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                   u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
+                                                   unsigned n_groups)
+{
+    __shared__ unsigned aft[UTM_AF_TILE_WORDS * 64];  // float32 bit patterns
+    __shared__ u64 live[UTM_AF_TILE_WORDS];
+    if (st->done) return;
+    unsigned tile, grp;
+    if (!tile_of_block(wp, UTM_AF_TILE_WORDS, n_groups, tile, grp)) return;
+    const u64 w0 = (u64)tile * UTM_AF_TILE_WORDS;
+    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
+    if (threadIdx.x < UTM_AF_TILE_WORDS) {
+        u64 c = covered[w0 + threadIdx.x];
+        if (wcol) {
+            c |= wcol[w0 + threadIdx.x];
+            if (grp == 0) covered[w0 + threadIdx.x] = c;
+        }
+        live[threadIdx.x] = ~c;
+    }
+    {
+        const v4u *src = reinterpret_cast<const v4u *>(af + w0 * 64);
+        v4u *dst = reinterpret_cast<v4u *>(aft);
+#pragma unroll
+        for (int i = 0; i < UTM_AF_TILE_WORDS * 16 / 256; ++i) dst[i * 256 + threadIdx.x] = src[i * 256 + threadIdx.x];
+    }
+    __syncthreads();
+
+    const unsigned n_active = st->n_active;
+    const unsigned lo = grp * group_size;
+    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u64 m0 = live[2 * lane], m1 = live[2 * lane + 1];
+    const unsigned *a0 = aft + (2 * lane) * 64, *a1 = a0 + 64;
+    constexpr int U = 4;
+    for (unsigned i0 = lo + wave * U; i0 < hi; i0 += 4 * U) {
+        unsigned s[U];
+        v2q x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u < hi ? i0 + u : hi - 1;  // tail: re-read the last sample, ignored below
+            s[u] = act[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            x[u] = __builtin_nontemporal_load(reinterpret_cast<const v2q *>(cols + (u64)s[u] * wp + w0) + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            u64 b0 = x[u].x & m0, b1 = x[u].y & m1;
+            const unsigned n_lane = __popcll(b0) + __popcll(b1);
+            if (i0 + u >= hi || __ballot(n_lane != 0) == 0) continue;  // wave uniform
+            u64 sum = 0;
+            while (b0) {
+                const unsigned bits = a0[__builtin_ctzll(b0)];
+                b0 &= b0 - 1;
+                sum += (u64)((bits & 0x7FFFFFu) | 0x800000u) << ((bits >> 23) - e_base);
+            }
+            while (b1) {
+                const unsigned bits = a1[__builtin_ctzll(b1)];
+                b1 &= b1 - 1;
+                sum += (u64)((bits & 0x7FFFFFu) | 0x800000u) << ((bits >> 23) - e_base);
+            }
+            const unsigned n = wave_sum_u32(n_lane);
+            const i64 total = wave_sum_u63(sum);  // per lane < 2^53 (the host's exactness precondition)
+            if (lane == 0) {
+                atomicAdd(&cnt[s[u]], (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s[u]]), (u64)total);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1-AF, sparse phase: once a good part of the variants is covered most loaded words are zero after
+// the AND, so this kernel is k_score_int's streaming loop (LDS-staged ~covered tile, 8 KiB in flight
+// per wave) plus a per-wave LDS queue: surviving bits only *enqueue* their variant index (prefix sum
+// over the lanes, no memory wait); when the queue fills up, and at the end of the (sample, tile), all
+// 64 lanes drain it together -- independent float32 gathers from the AF table in global memory (it
+// stays in L2 / Infinity Cache), mantissa << exponent, 64-bit add -- then ONE reduction per (sample,
+// tile).  The host switches from k_score_afq to this kernel when the captured fraction passes
+// UTM_AF_SWITCH.  Same integer sums, same exactness argument.
+// ------------------------------------------------------------------------------------------------
+// queue entries per wave: STEPS KiB of ~covered + 4 queues must leave room for 4-5 workgroups per CU
+__device__ __forceinline__ u64 af_fixed(unsigned f, int e_base)
+{
+    return (u64)((f & 0x7FFFFFu) | 0x800000u) << ((f >> 23) - e_base);
+}
+
+// CAP = queue depth per LANE: every lane keeps its own little queue (slot-major in LDS, so a wave's
+// pushes are conflict free) -- no cross-lane prefix sum is needed to place an entry.
+// delta_mask == nullptr: full scoring against ~covered (adds to the accumulators, fuses the pending update).
+// delta_mask != nullptr: *delta* scoring -- the mask holds the variants the last winner newly covered
+// (k_newly_mask made it and already updated covered); their contribution is SUBTRACTED from the persistent
+// accumulators.  Same bytes streamed, but only the few newly covered bits take the queue/gather path.
+template <int STEPS, int CAP>
+__global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+                                                   const unsigned *__restrict__ afbits, int e_base, const Pending pend,
+                                                   const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                   u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
+                                                   unsigned n_groups, const u64 *__restrict__ delta_mask)
+{
+    __shared__ v4u live[STEPS * 64];
+    __shared__ unsigned queue[4][CAP][64];
+    if (st->done) return;
+    unsigned tile, grp;
+    if (!tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp)) return;
+    const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
+    const u64 left = (wp - w0) / UTM_STEP_WORDS;
+    const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
+    if (delta_mask) {
+        const v4u *mk = reinterpret_cast<const v4u *>(delta_mask + w0);
+        for (int i = threadIdx.x; i < nsteps * 64; i += 256) live[i] = mk[i];
+    } else {
+        v4u *cv = reinterpret_cast<v4u *>(covered + w0);
+        const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
+        const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
+        for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
+            v4u c = cv[i];
+            if (wc) {
+                c |= wc[i];
+                if (grp == 0) cv[i] = c;
+            }
+            live[i] = ~c;
+        }
+    }
+    __syncthreads();
+
+    const unsigned n_active = st->n_active;
+    const unsigned lo = grp * group_size;
+    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int U = STEPS < 8 ? STEPS : 8;
+    unsigned(*q)[64] = queue[wave];
+    const unsigned *af_tile = afbits + w0 * 64;  // AF of the tile's first variant
+    for (unsigned i = lo + wave; i < hi; i += 4) {
+        const unsigned s = act[i];
+        const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
+        unsigned acc = 0, qc = 0;  // qc: entries in this lane's queue
+        u64 sum = 0;
+        auto drain = [&]() {
+            for (unsigned j = 0; __ballot(j < qc) != 0; j += 2) {  // two independent gathers per round
+                const unsigned f0 = j < qc ? af_tile[q[j][lane]] : 0u;
+                const unsigned f1 = j + 1 < qc ? af_tile[q[j + 1][lane]] : 0u;
+                if (j < qc) sum += af_fixed(f0, e_base);
+                if (j + 1 < qc) sum += af_fixed(f1, e_base);
+            }
+            qc = 0;
+        };
+        for (int j0 = 0; j0 < nsteps; j0 += U) {
+            v4u b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                b[u] = j0 + u < nsteps ? __builtin_nontemporal_load(p + (j0 + u) * 64) : (v4u)(0);
+            unsigned nb = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j0 + u < nsteps) b[u] &= live[(j0 + u) * 64 + lane];
+                nb += __popc(b[u].x) + __popc(b[u].y) + __popc(b[u].z) + __popc(b[u].w);
+            }
+            acc += nb;
+            if (__ballot(nb != 0) == 0) continue;  // nothing survived in these 8 KiB
+            if (__ballot(qc + nb > CAP) != 0) drain();
+            const unsigned base = (unsigned)(j0 * UTM_STEP_WORDS + 2 * lane) * 64;  // variant offset inside the tile
+            if (__ballot(nb > CAP) == 0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (__ballot((b[u].x | b[u].y | b[u].z | b[u].w) != 0) == 0) continue;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned bits = b[u][d];
+                        const unsigned v0 = base + u * (UTM_STEP_WORDS * 64) + d * 32;
+                        while (bits) {
+                            q[qc++][lane] = v0 + __builtin_ctz(bits);
+                            bits &= bits - 1;
+                        }
+                    }
+                }
+            } else {  // dense data: some lane has more bits in one batch than its queue holds -- gather directly
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned bits = b[u][d];
+                        const unsigned v0 = base + u * (UTM_STEP_WORDS * 64) + d * 32;
+                        while (bits) {
+                            sum += af_fixed(af_tile[v0 + __builtin_ctz(bits)], e_base);
+                            bits &= bits - 1;
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(qc != 0) != 0) drain();
+        const unsigned n = wave_sum_u32(acc);
+        if (n) {  // wave uniform
+            const i64 total = wave_sum_u63(sum);
+            if (lane == 0) {  // two's complement: adding the negated value subtracts
+                atomicAdd(&cnt[s], delta_mask ? (u64)0 - (u64)n : (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), delta_mask ? (u64)0 - (u64)total : (u64)total);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sequential AF (float64 AF, or float32 AF that fails the fixed-point precondition): the reference
+// adds row values into a float64 score in ascending variant order (`scores += row`, select.py:40);
+// float64 addition does not reassociate, so each sample's chain is walked by ONE lane, chunk after
+// chunk, word after word, bit after bit.  Latency bound by construction.
+// ------------------------------------------------------------------------------------------------
+template <typename AF_T>
+__global__ __launch_bounds__(64) void k_score_seq(const SeqChunk *__restrict__ chunks, int n_chunks,
+                                                  const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                  u64 *__restrict__ cnt, double *__restrict__ fscore, int only_on_overflow)
+{
+    if (st->done) return;
+    if (only_on_overflow && !(st->need_chain && st->cand_overflow)) return;
+    const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= st->n_active) return;
+    const unsigned s = act[i];
+    double acc = 0.0;
+    u64 n = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const SeqChunk ch = chunks[c];
+        const ulonglong2 *col = reinterpret_cast<const ulonglong2 *>(ch.cols + (u64)s * ch.wp);
+        const ulonglong2 *cov = reinterpret_cast<const ulonglong2 *>(ch.covered);
+        const AF_T *af = static_cast<const AF_T *>(ch.af);
+        for (u64 w2 = 0; w2 < (ch.w + 1) / 2; ++w2) {  // wp is even, padding words are zero
+            const ulonglong2 x = col[w2];
+            const ulonglong2 m = cov[w2];
+            u64 b0 = x.x & ~m.x, b1 = x.y & ~m.y;
+            n += __popcll(b0) + __popcll(b1);
+            const AF_T *a = af + w2 * 128;
+            while (b0) { acc += (double)a[__builtin_ctzll(b0)]; b0 &= b0 - 1; }
+            a += 64;
+            while (b1) { acc += (double)a[__builtin_ctzll(b1)]; b1 &= b1 - 1; }
+        }
+    }
+    cnt[s] = n;
+    fscore[s] = acc;
+}

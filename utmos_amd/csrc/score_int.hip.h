@@ -1,0 +1,91 @@
+// K1, integer scores: the bandwidth-bound bitset reduction (and the XCD-aware block -> tile map).
+#pragma once
+#include "common.hip.h"
+
+// XCD-aware block -> (tile, group) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+// b + 8 share one; each XCD has its own L2).  The (tile, group) units are numbered tile-major and cut into
+// 8 equal contiguous ranges, one per XCD: an XCD walks whole variant tiles (all sample groups of a tile one
+// after the other), so a tile's ~covered words and the pending winner's words are fetched into ONE L2 and
+// reused there, while every XCD still gets the same number of units.  Grid = 8 * ceil(units / 8); surplus
+// blocks return.  Only speed depends on the placement, never results.
+__device__ __forceinline__ bool tile_of_block(u64 wp, unsigned tile_words, unsigned n_groups, unsigned &tile, unsigned &grp)
+{
+    const unsigned n_tiles = (unsigned)((wp + tile_words - 1) / tile_words);
+    const unsigned units = n_tiles * n_groups, per_xcd = (units + 7) / 8;
+    const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const unsigned u = xcd * per_xcd + j;
+    tile = u / n_groups;
+    grp = u % n_groups;
+    return j < per_xcd && u < units;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: integer scores.  count[s] += popcount(col_s & ~covered) over one tile of the variant axis,
+// for one group of selectable samples (calculate_scores' row loop, select.py:37-41, as a bitset
+// reduction).  Grid = tiles x groups.  The workgroup stages ~covered for its tile in LDS once
+// (fusing the pending `covered |= winner` of the previous iteration, select.py:100), then each of
+// its 4 waves streams whole samples through that tile: one global_load_dwordx4 (1 KiB per wave)
+// + one ds_read_b128 + 4x(v_and, v_bcnt) per step, a wave reduction and ONE 64-bit atomic per
+// (sample, tile).  Integer adds: exact and order independent.
+// ------------------------------------------------------------------------------------------------
+template <int STEPS, bool NT>
+__global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+                                                   const Pending pend,
+                                                   const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                   u64 *__restrict__ cnt, unsigned group_size, unsigned n_groups)
+{
+    __shared__ v4u live[STEPS * 64];  // ~covered of this tile, STEPS KiB
+    if (st->done) return;
+    unsigned tile, grp;
+    if (!tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp)) return;
+    const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
+    const u64 left = (wp - w0) / UTM_STEP_WORDS;
+    const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
+
+    v4u *cv = reinterpret_cast<v4u *>(covered + w0);
+    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
+    const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
+    for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
+        v4u c = cv[i];
+        if (wc) {
+            c |= wc[i];
+            // every group of this tile computes the same words; group 0 stores them.  A racing reader
+            // sees old or new words and ORs the winner in itself, so either is right.
+            if (grp == 0) cv[i] = c;
+        }
+        live[i] = ~c;
+    }
+    __syncthreads();
+
+    const unsigned n_active = st->n_active;
+    const unsigned lo = grp * group_size;
+    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int U = STEPS < 8 ? STEPS : 8;  // loads in flight per wave: U KiB
+    for (unsigned i = lo + wave; i < hi; i += 4) {
+        const unsigned s = act[i];
+        const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
+        unsigned acc = 0;
+        if (nsteps == STEPS) {
+#pragma unroll 1
+            for (int j0 = 0; j0 < STEPS; j0 += U) {
+                v4u x[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    x[u] = NT ? __builtin_nontemporal_load(p + (j0 + u) * 64) : p[(j0 + u) * 64];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const v4u b = x[u] & live[(j0 + u) * 64 + lane];
+                    acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+                }
+            }
+        } else {
+            for (int j = 0; j < nsteps; ++j) {
+                const v4u b = p[j * 64] & live[j * 64 + lane];
+                acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+            }
+        }
+        acc = wave_sum_u32(acc);
+        if (lane == 0 && acc) atomicAdd(&cnt[s], (u64)acc);
+    }
+}
