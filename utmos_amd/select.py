@@ -307,6 +307,9 @@ _MEMORY = [
     (("--buffer",), dict(type=int, default=32768, help="variants per HBM chunk when chunking is on [%(default)s]")),
     (("--maxmem",), dict(type=int, default=2, help="GB one chunk may take; 0 = always chunk [%(default)s]")),
     (("--device",), dict(type=int, default=0, help="GPU index [%(default)s]")),
+    (("--brute-force",), dict(action="store_true",
+                             help="re-score every sample from scratch in every iteration (default: later iterations only "
+                                  "subtract what the last winner newly captured; identical output)")),
 ]
 
 
@@ -374,6 +377,8 @@ def select_main(cmdargs):
     shard = (rank, world) if world > 1 else None
     dev = local_rank if world > 1 and "--device" not in cmdargs else args.device
     data = load_files(args.in_files, args.lowmem, args.buffer, args.af, dev, shard)
+    if not args.brute_force:
+        data["data"].set_decremental(True)      # exact; same rows (DESIGN.md "Decremental scoring")
     transport = None
     if world > 1:
         matrix = data["data"]
