@@ -42,6 +42,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
     p.add_argument("--no-roofline-pass", action="store_true")
+    p.add_argument("--af-estimate-scores", action="store_true",
+                   help="AF: do not chain unambiguous winners (same rows; reported scores are estimates)")
     p.add_argument("--decremental", action="store_true",
                    help="SURVEY 8f-4 shortcut (exact, reads far fewer bytes): reported separately, never the default")
     p.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip rank 0's single-GPU re-run and comparison")
@@ -157,6 +159,8 @@ def main():
     k_sel = n_total if args.select < 0 else min(args.select, n_total)
     if args.decremental:
         m.set_decremental(True)
+    if args.af_estimate_scores:
+        m.set_af_exact_scores(False)
 
     def one_step():
         m.reset()

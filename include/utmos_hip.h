@@ -140,6 +140,13 @@ int utm_get_stats(utm_ctx *ctx, utm_stats *out);
  * are reported separately from the brute-force roofline.  threshold = largest fraction of a column's
  * words that may be newly covered for an iteration to go decremental (<= 0: default 0.05). */
 int utm_set_decremental(utm_ctx *ctx, int32_t on, double threshold);
+/* AF modes: the winner of an iteration is always the reference's (sample order, new_count are exact).  The reported
+ * *score* is, by default (on = 1), also the reference's float64 running sum bit for bit, which costs one sequential
+ * chain per iteration whenever the parallel sum is not provably exact.  on = 0 skips that chain when the winner is
+ * unambiguous and reports the parallel estimate (relative error <= 2^-24 + n 2^-53) -- what a caller that only
+ * writes the reference's TSV columns needs.  Ambiguous iterations (ties within the error bound) are always chained,
+ * and so is everything on a context that holds only a shard of the samples (its records meet other shards'). */
+int utm_set_af_exact_scores(utm_ctx *ctx, int32_t on);
 /* Switch per-launch HIP-event timing of the scoring kernels on/off (same as UTM_FLAG_PROFILE_EVENTS). */
 int utm_set_profile(utm_ctx *ctx, int32_t on);
 

@@ -604,3 +604,30 @@ def test_generator_and_scoring_do_not_depend_on_the_chunk_layout_at_large_sizes(
     assert (out[0][0] == out[1][0]).all() and out[0][1:] == out[1][1:]
     assert out[0][0].min() > 0 and out[0][2][0] == out[0][0].max()      # every sample has data; first gain = largest column
     assert abs(out[0][0].sum() / (n_var * n_samp) - 0.11) < 0.03           # the generator's mean density (14 octaves)
+
+
+@pytest.mark.parametrize("kind", ["f32_beyond_exact", "f64"])
+def test_af_estimate_scores_mode_keeps_the_rows(dev, kind):
+    """utm_set_af_exact_scores(0): unambiguous winners are not chained -- indices and counts stay the oracle's, the
+    reported scores are estimates within the stated bound."""
+    rng = np.random.default_rng(40)
+    n_var, n_samp = 12000, 80
+    dense = rng.random((n_var, n_samp)) < 0.3
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    dense[:, 1] = dense[:, 0]                                  # an exact tie: must still be resolved like the reference
+    if kind == "f64":
+        af = rng.random(n_var) * 0.5 + 1e-3
+    else:
+        af = np.exp2(rng.uniform(-12, -8, n_var)).astype(np.float32)
+        af[:40] = np.float32(2.0 ** -30)
+    cols = npo.pack_columns(dense)
+    state = np.ones(n_samp, np.uint8)
+    exp = ou.c_greedy(cols, n_var, state, af=af)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols)
+        m.set_af(c, af)
+        m.set_af_exact_scores(False)
+        idx, new, score = m.run(n_samp)
+    assert idx.tolist() == exp[0].tolist() and new.tolist() == exp[1].tolist()
+    assert np.allclose(score, exp[2], rtol=1e-6, atol=0)

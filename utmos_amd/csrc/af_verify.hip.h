@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
     if (threadIdx.x == 0) {
         st->n_cand = n_c < UTM_MAX_CAND ? (int)n_c : UTM_MAX_CAND;
         st->cand_overflow = n_c > UTM_MAX_CAND;
-        st->need_chain = inexact;
+        // one candidate only: the argmax is settled (its estimate is also the largest); its exact float64 sum is
+        // needed just for the reported score, which the caller may not want
+        st->need_chain = inexact && !(a.af_skip_single && n_c == 1);
         st->all_exact = !any_inexact;
     }
 }

@@ -163,6 +163,7 @@ struct utm_ctx {
     i64 scored = 0;           // scoring passes run (>= iter)
     unsigned active_ub = 0;   // upper bound of local selectable samples (exact while the loop is alive)
     i64 captured_seen = 0;    // tot_captured as of the last sync
+    bool af_exact_scores = true; // chain a lone candidate too, so that the reported score is the reference's exact float64 sum
     bool af_all_exact = false; // latched from the device: AF estimates are exact from here on (no candidates needed)
     bool finished = false;
 
@@ -750,6 +751,8 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     a.peer_mbox = c->d_peer_mbox;
     a.cand = (c->af_mode != UTM_AF_NONE && c->af_fixed && !c->af_all_exact) ? c->d_cand : nullptr;
     a.af_is_f64 = c->af_mode == UTM_AF_F64;
+    // (a shard's record is compared with other shards' records: there the score has to be exact)
+    a.af_skip_single = (!c->af_exact_scores && c->n_local == c->n_total) ? 1 : 0;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
     a.slot_words = c->xbuf_slot_words;
     a.res_idx = c->d_res_idx;
@@ -1196,6 +1199,13 @@ extern "C" int utm_set_decremental(utm_ctx *c, int32_t on, double threshold)
     c->decr_enabled = on != 0;
     c->decr_threshold = threshold > 0 ? threshold : 0.05;
     c->prepared = false;  // buffers are allocated at the next reset
+    return UTM_OK;
+}
+
+extern "C" int utm_set_af_exact_scores(utm_ctx *c, int32_t on)
+{
+    CTX(c);
+    c->af_exact_scores = on != 0;
     return UTM_OK;
 }
 

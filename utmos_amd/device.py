@@ -161,6 +161,10 @@ class DeviceMatrix:
         """Allow decremental scoring for later iterations (exact; fewer bytes; reported separately)."""
         nat.check(nat.lib().utm_set_decremental(self._h, 1 if on else 0, float(threshold)))
 
+    def set_af_exact_scores(self, on):
+        """AF modes: off = skip the sequential chain of an unambiguous winner (same rows; scores become estimates)."""
+        nat.check(nat.lib().utm_set_af_exact_scores(self._h, 1 if on else 0))
+
     def set_profile(self, on):
         nat.check(nat.lib().utm_set_profile(self._h, 1 if on else 0))
 

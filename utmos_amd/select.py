@@ -379,6 +379,7 @@ def select_main(cmdargs):
     data = load_files(args.in_files, args.lowmem, args.buffer, args.af, dev, shard)
     if not args.brute_force:
         data["data"].set_decremental(True)      # exact; same rows (DESIGN.md "Decremental scoring")
+    data["data"].set_af_exact_scores(False)     # the TSV has no score column: only ambiguous argmaxes need their chains
     transport = None
     if world > 1:
         matrix = data["data"]
