@@ -216,23 +216,35 @@ def test_multi_chunk_equals_single_chunk(dev):
     check_run(dev, dense, chunks=bounds, af=af64)
 
 
-def test_step_peek_and_covered(dev):
+@pytest.mark.parametrize("af_kind", [None, "f32", "f64"])
+def test_step_peek_and_covered(dev, af_kind):
+    """step / peek_scores / covered interleaved: peeks and covered reads apply the pending winner outside the loop,
+    so the persistent AF accumulators (and the decremental counts) must be rebuilt afterwards."""
     rng = np.random.default_rng(13)
     n_var, n_samp = 5000, 40
     dense = ou.random_dense(rng, n_var, n_samp)
     cols = npo.pack_columns(dense)
+    af = None
+    if af_kind:
+        af = dense.sum(axis=1) / (2.0 * n_samp)
+        af = af.astype(np.float32) if af_kind == "f32" else af / 3.0
     state = np.ones(n_samp, np.uint8)
     with make_matrix(dev, cols, n_var) as m:
+        if af is not None:
+            m.set_af(0, af)
+        m.set_decremental(True, 1.0)
         covered = np.zeros(cols.shape[1], np.uint64)
-        for _ in range(6):
-            best, cnt, sc = ou.c_score(cols, n_var, state)
-            counts, scores = m.peek_scores()
-            assert counts.tolist() == cnt.tolist() and scores.tolist() == sc.tolist()
+        for it in range(8):
+            best, cnt, sc = ou.c_score(cols, n_var, state, af=af)
+            if it % 2 == 0:
+                counts, scores = m.peek_scores()
+                assert counts.tolist() == cnt.tolist() and scores.tolist() == sc.tolist()
             got = m.step()
-            assert got is not None and got[0] == best and got[1] == cnt[best]
+            assert got is not None and got[0] == best and got[1] == cnt[best] and got[2] == sc[best]
             state[best] = 0
             covered |= cols[best]
-            assert (m.covered(0) == covered).all()
+            if it % 3 == 0:
+                assert (m.covered(0) == covered).all()
 
 
 def test_golden_fixtures_through_the_device(dev):
