@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip rank 0's single-GPU re-run and comparison")
     p.add_argument("--exchange", choices=["auto", "rccl"], default="auto",
                    help="N > 1: auto = device mailboxes over hipIpc mappings when every rank can, else RCCL; rccl = force RCCL")
+    p.add_argument("--decr-threshold", type=float, default=0.0, help="--decremental: newly-covered word fraction below which an iteration goes decremental (0 = library default)")
     p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the exchange path)")
     return p.parse_args()
 
@@ -158,7 +159,7 @@ def main():
 
     k_sel = n_total if args.select < 0 else min(args.select, n_total)
     if args.decremental:
-        m.set_decremental(True)
+        m.set_decremental(True, args.decr_threshold)
     if args.af_estimate_scores:
         m.set_af_exact_scores(False)
 

@@ -138,7 +138,7 @@ int utm_get_stats(utm_ctx *ctx, utm_stats *out);
  * contribution of the variants the last winner newly covered (counts and fixed-point AF sums stay exact;
  * same rows).  Reads far fewer bytes than the brute-force loop, so it is off by default and its numbers
  * are reported separately from the brute-force roofline.  threshold = largest fraction of a column's
- * words that may be newly covered for an iteration to go decremental (<= 0: default 0.05). */
+ * words that may be newly covered for an iteration to go decremental (<= 0: default 0.2). */
 int utm_set_decremental(utm_ctx *ctx, int32_t on, double threshold);
 /* AF modes: the winner of an iteration is always the reference's (sample order, new_count are exact).  The reported
  * *score* is, by default (on = 1), also the reference's float64 running sum bit for bit, which costs one sequential

@@ -141,7 +141,7 @@ struct utm_ctx {
     unsigned *d_listn = nullptr; // per chunk
     size_t listn_cap = 0;
     bool decr_enabled = false;
-    double decr_threshold = 0.05;
+    double decr_threshold = 0.2;
     bool keep_valid = false;     // the persistent counts describe the state right before the pending winner
     i64 last_new = -1;           // new_count of the last row (host copy)
     i64 decr_iterations = 0;
@@ -1053,7 +1053,10 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     i64 enq = 0;
     while (enq < k_max && !c->finished) {
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
-        const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, 8) : batch;
+        // ... and so is the switch to decremental iterations
+        const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, 8)
+                               : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, 16)
+                                                                                            : batch;
         const i64 n = std::min<i64>(this_batch, k_max - enq);
         const unsigned a0 = c->active_ub;
         // Decremental batches: only when allowed, when the persistent counts are current, and when the last
@@ -1197,7 +1200,7 @@ extern "C" int utm_set_decremental(utm_ctx *c, int32_t on, double threshold)
 {
     CTX(c);
     c->decr_enabled = on != 0;
-    c->decr_threshold = threshold > 0 ? threshold : 0.05;
+    c->decr_threshold = threshold > 0 ? threshold : 0.2;
     c->prepared = false;  // buffers are allocated at the next reset
     return UTM_OK;
 }
