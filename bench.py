@@ -261,6 +261,7 @@ def main():
         "scoring": "decremental after the first passes (bytes = what this variant actually reads; NOT the brute-force "
                    "roofline metric)" if args.decremental else "brute force: every selectable column re-read every iteration",
         "decremental_iterations_per_step": st["decr_iterations"] if args.decremental else 0,
+        "decremental_interleaved_copy_bytes": st["decr_interleaved_bytes"] if args.decremental else 0,
         "brute_force_equivalent_gbps": st["brute_force_bytes"] * world * args.steps / elapsed / 1e9,
         "hbm_gbps_whole_loop": whole_loop_gbps, "hbm_frac_whole_loop": whole_loop_gbps / (HBM_PEAK_GBPS * world),
         "device_loop_ms_per_step": loop_ms / max(1, args.steps),

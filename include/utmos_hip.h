@@ -75,6 +75,7 @@ typedef struct utm_stats {
     int32_t n_chunks;
     int64_t decr_iterations;   /* iterations scored decrementally (0 unless enabled) */
     int64_t brute_force_bytes; /* what full re-scoring of every iteration would have had to read */
+    int64_t decr_interleaved_bytes; /* HBM held by the word-interleaved copy the decremental iterations stream (0: gather form) */
 } utm_stats;
 
 const char *utm_last_error(void);
@@ -137,8 +138,12 @@ int utm_get_stats(utm_ctx *ctx, utm_stats *out);
 /* Decremental scoring: after a full scoring pass, later iterations only subtract the
  * contribution of the variants the last winner newly covered (counts and fixed-point AF sums stay exact;
  * same rows).  Reads far fewer bytes than the brute-force loop, so it is off by default and its numbers
- * are reported separately from the brute-force roofline.  threshold = largest fraction of a column's
- * words that may be newly covered for an iteration to go decremental (<= 0: default 0.2). */
+ * are reported separately from the brute-force roofline.  When free HBM allows, the context keeps a
+ * second, word-interleaved copy of the matrix (rows_t[word][sample]) for these iterations: a newly
+ * covered word is then one contiguous read over all samples instead of one 8-byte gather per column
+ * (utm_stats.decr_interleaved_bytes; UTM_DECR_INTERLEAVED=0 or lack of room keeps the gather form).
+ * threshold = largest fraction of a column's words that may be newly covered for an iteration to go
+ * decremental (<= 0: default -- 0.5 with the interleaved copy, 0.2 gathering). */
 int utm_set_decremental(utm_ctx *ctx, int32_t on, double threshold);
 /* AF modes: the winner of an iteration is always the reference's (sample order, new_count are exact).  The reported
  * *score* is, by default (on = 1), also the reference's float64 running sum bit for bit, which costs one sequential

@@ -477,10 +477,13 @@ def test_two_processes_share_the_gpu_host_staged_exchange(dev):
     assert all(r[1] for r in res) and res[0][2] == res[1][2] > 50
 
 
+@pytest.mark.parametrize("layout", ["interleaved", "gather"])
 @pytest.mark.parametrize("mode", ["int", "weights", "af32", "af64", "chunks"])
-def test_decremental_scoring_gives_the_same_rows(dev, mode):
+def test_decremental_scoring_gives_the_same_rows(dev, mode, layout, monkeypatch):
     """later iterations only subtract what the last winner newly covered; same rows, and the
-    device really ran decremental iterations."""
+    device really ran decremental iterations -- streaming the word-interleaved copy, or gathering from the
+    columns (what a context without room for the copy runs)."""
+    monkeypatch.setenv("UTM_DECR_INTERLEAVED", "1" if layout == "interleaved" else "0")
     rng = np.random.default_rng(30)
     n_var, n_samp = 64 * 128 * 6 + 99, 150
     dense = ou.random_dense(rng, n_var, n_samp)
@@ -498,6 +501,7 @@ def test_decremental_scoring_gives_the_same_rows(dev, mode):
     _, stats = check_run(dev, dense, state=state, decremental=1.0, **kw)   # threshold 1.0: decremental from the 2nd batch on
     assert stats["decr_iterations"] > 0
     assert stats["algo_bytes"] < stats["brute_force_bytes"]
+    assert (stats["decr_interleaved_bytes"] > 0) == (layout == "interleaved")
 
 
 def test_decremental_survives_peek_and_covered_reads(dev):
@@ -565,7 +569,7 @@ def test_full_size_select_all_invariants(dev, decremental):
         assert rows[False] == rows[True]
 
 
-def test_randomised_configurations_against_the_oracle(dev):
+def test_randomised_configurations_against_the_oracle(dev, monkeypatch):
     """Seeded sweep over shapes, chunkings, sample states, weights, AF modes and the decremental switch:
     every configuration must give the oracle's indices, counts and float64 scores."""
     import os
@@ -599,13 +603,15 @@ def test_randomised_configurations_against_the_oracle(dev):
             chunks = [0] + cuts + [n_var]
         k = int(rng.integers(1, n_samp + 1))
         decr = 1.0 if rng.random() < 0.4 else None
+        gather = bool(rng.random() < 0.4)
+        monkeypatch.setenv("UTM_DECR_INTERLEAVED", "0" if gather else "1")
         est = mode != "none" and rng.random() < 0.3
         try:
             check_run(dev, dense, state=state, weights=weights, af=af, k=k, chunks=chunks, decremental=decr,
                       estimate_scores=est)
         except AssertionError as e:
             raise AssertionError(f"trial {trial}: n_var={n_var} n_samp={n_samp} density={density} mode={mode} "
-                                 f"chunks={chunks} k={k} decr={decr} weights={'yes' if weights is not None else 'no'}") from e
+                                 f"chunks={chunks} k={k} decr={decr} gather={gather} weights={'yes' if weights is not None else 'no'}") from e
 
 
 def test_generator_and_scoring_do_not_depend_on_the_chunk_layout_at_large_sizes(dev):

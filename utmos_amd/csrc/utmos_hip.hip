@@ -105,6 +105,8 @@ struct Chunk {
     u64 *mask = nullptr;           // AF delta scoring: per word, the bits the last winner newly covered
     unsigned *list_idx = nullptr;  // decremental scoring: words newly covered by the last winner
     u64 *list_val = nullptr;
+    u64 *rows_t = nullptr;         // decremental scoring: word-interleaved copy [wp][s_t] (optional: needs the room)
+    bool rows_t_valid = false;
     std::vector<float> h_af32;
     std::vector<double> h_af64;
 };
@@ -141,7 +143,8 @@ struct utm_ctx {
     unsigned *d_listn = nullptr; // per chunk
     size_t listn_cap = 0;
     bool decr_enabled = false;
-    double decr_threshold = 0.2;
+    bool decr_interleaved = false;  // the chunks carry a word-interleaved copy: decremental iterations stream it
+    double decr_threshold = 0;  // <= 0: by layout (0.5 streaming the interleaved copy, 0.2 gathering)
     bool keep_valid = false;     // the persistent counts describe the state right before the pending winner
     i64 last_new = -1;           // new_count of the last row (host copy)
     i64 decr_iterations = 0;
@@ -264,6 +267,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
         if ((void *)ch.af32 != ch.af) (void)hipFree(ch.af32);
         (void)hipFree(ch.af);
         (void)hipFree(ch.list_idx);
+        (void)hipFree(ch.rows_t);
         (void)hipFree(ch.list_val);
         (void)hipFree(ch.mask);
     }
@@ -341,6 +345,7 @@ extern "C" int utm_upload_columns(utm_ctx *c, int32_t chunk, uint32_t first_col,
     HIP_TRY(hipMemcpy2DAsync(ch->cols + (u64)first_col * ch->wp, ch->wp * 8, cols, stride_words * 8, ch->w * 8, n_cols,
                              hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    ch->rows_t_valid = false;
     c->prepared = false;
     c->varcount_valid = false;
     return UTM_OK;
@@ -385,6 +390,7 @@ extern "C" int utm_upload_rows_packed(utm_ctx *c, int32_t chunk, uint64_t first_
         if (e != hipSuccess) rc = fail(UTM_EHIP, "row transpose: %s", hipGetErrorString(e));
     }
     (void)hipFree(d_rows);
+    ch->rows_t_valid = false;
     c->prepared = false;
     c->varcount_valid = false;
     return rc;
@@ -423,6 +429,7 @@ extern "C" int utm_synth_fill(utm_ctx *c, int32_t chunk, uint64_t seed, uint64_t
                        c->n_total, c->first, utm_octaves(c->n_total), ch->w, c->n_local);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
+    ch->rows_t_valid = false;
     c->prepared = false;
     c->varcount_valid = false;
     return UTM_OK;
@@ -645,6 +652,62 @@ static int ensure_xbuf(utm_ctx *c, int n_ranks)
     return UTM_OK;
 }
 
+// Decremental mode: the word-interleaved second copy of every chunk (decremental.hip.h), all chunks or none, only
+// when it fits next to a reserve of free HBM.  UTM_DECR_INTERLEAVED=0 keeps the gather form (what a context
+// without the room runs).
+static u64 interleaved_stride(const utm_ctx *c) { return round_up((u64)c->n_local, 64); }
+
+static int ensure_interleaved(utm_ctx *c)
+{
+    const char *env = getenv("UTM_DECR_INTERLEAVED");  // read per reset: tests flip it
+    const bool wanted = !(env && *env == '0');
+    const u64 s_t = interleaved_stride(c);
+    bool have_all = true;
+    u64 need = 0;
+    for (auto &ch : c->chunks)
+        if (!ch.rows_t) {
+            have_all = false;
+            need += ch.wp * s_t * 8;
+        }
+    if (!have_all || !wanted) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const bool fits = (u64)free_b > need + (4ull << 30);
+        if (!wanted || !fits) {
+            for (auto &ch : c->chunks) {
+                (void)hipFree(ch.rows_t);
+                ch.rows_t = nullptr;
+                ch.rows_t_valid = false;
+            }
+            c->decr_interleaved = false;
+            return UTM_OK;
+        }
+        for (auto &ch : c->chunks)
+            if (!ch.rows_t) {
+                if (hipMalloc(&ch.rows_t, ch.wp * s_t * 8) != hipSuccess) {
+                    (void)hipGetLastError();
+                    for (auto &o : c->chunks) {
+                        (void)hipFree(o.rows_t);
+                        o.rows_t = nullptr;
+                        o.rows_t_valid = false;
+                    }
+                    c->decr_interleaved = false;
+                    return UTM_OK;
+                }
+                ch.rows_t_valid = false;
+            }
+    }
+    for (auto &ch : c->chunks)
+        if (!ch.rows_t_valid) {
+            hipLaunchKernelGGL(k_interleave, dim3((unsigned)(ch.wp / 64), (unsigned)(s_t / 64)), dim3(256), 0, c->stream, ch.cols,
+                               ch.wp, c->n_local, s_t, ch.rows_t);
+            ch.rows_t_valid = true;
+        }
+    HIP_TRY(hipGetLastError());
+    c->decr_interleaved = true;
+    return UTM_OK;
+}
+
 extern "C" int utm_reset(utm_ctx *c)
 {
     CTX(c);
@@ -691,6 +754,7 @@ extern "C" int utm_reset(utm_ctx *c)
                 HIP_TRY(hipMalloc(&ch.list_val, ch.wp * 8));
             }
         HIP_TRY(hipMemsetAsync(c->d_listn, 0, c->chunks.size() * 4, c->stream));
+        TRY(ensure_interleaved(c));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->keep_valid = false;
@@ -934,17 +998,34 @@ static int enqueue_score_decr(utm_ctx *c)
     const bool af = c->af_mode != UTM_AF_NONE;  // (k_pick clears the list counters after reading them)
     unsigned split = (2048 + a_ub - 1) / a_ub;
     split = std::min(16u, std::max(1u, split));
+    const u64 s_t = interleaved_stride(c);
+    // interleaved form: list slices sized from the last known gain (gains shrink over a run; any value is correct)
+    const unsigned slices = (unsigned)std::min<i64>(256, std::max<i64>(1, c->last_new / 16));
     for (size_t k = 0; k < c->chunks.size(); ++k) {
         Chunk &ch = c->chunks[k];
-        hipLaunchKernelGGL(k_newly, dim3((unsigned)std::min<u64>(2048, (ch.wp + 255) / 256)), dim3(256), 0, c->stream, ch.covered,
+        hipLaunchKernelGGL(k_newly, dim3((unsigned)std::min<u64>(1024, (ch.wp / 2 + 511) / 512)), dim3(512), 0, c->stream, ch.covered,
                            ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, ch.list_idx, ch.list_val, c->d_listn + k);
+        const unsigned *afbits = af ? reinterpret_cast<const unsigned *>(ch.af32) : nullptr;
+        const int e_base = af ? 150 - c->af_q : 0;
+        u64 *cnt = af ? c->d_cnt : c->d_cnt_keep;
+        i64 *afsum = af ? c->d_afsum : c->d_afsum_keep;
+        if (c->decr_interleaved) {
+            const dim3 grid((unsigned)((s_t + 255) / 256), slices);
+            if (af)
+                hipLaunchKernelGGL(k_decr_t<true>, grid, dim3(256), 0, c->stream, ch.rows_t, s_t, afbits, e_base, c->d_st, c->d_state,
+                                   c->n_local, ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
+            else
+                hipLaunchKernelGGL(k_decr_t<false>, grid, dim3(256), 0, c->stream, ch.rows_t, s_t, afbits, e_base, c->d_st, c->d_state,
+                                   c->n_local, ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
+            continue;
+        }
         const dim3 grid((a_ub + 3) / 4, split);
         if (af)
-            hipLaunchKernelGGL(k_decr<true>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, reinterpret_cast<const unsigned *>(ch.af32),
-                               150 - c->af_q, c->d_st, c->d_act, ch.list_idx, ch.list_val, c->d_listn + k, c->d_cnt, c->d_afsum);
+            hipLaunchKernelGGL(k_decr<true>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, afbits, e_base, c->d_st, c->d_act,
+                               ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
         else
-            hipLaunchKernelGGL(k_decr<false>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, (const unsigned *)nullptr, 0, c->d_st,
-                               c->d_act, ch.list_idx, ch.list_val, c->d_listn + k, c->d_cnt_keep, c->d_afsum_keep);
+            hipLaunchKernelGGL(k_decr<false>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, afbits, e_base, c->d_st, c->d_act,
+                               ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
     }
     HIP_TRY(hipGetLastError());
     return UTM_OK;
@@ -1062,7 +1143,8 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // Decremental batches: only when allowed, when the persistent counts are current, and when the last
         // winner newly covered few enough variants (gains shrink over a greedy run, so it stays that way).
         const bool decr = c->decr_enabled && c->keep_valid && c->last_new >= 0 && (c->af_mode == UTM_AF_NONE || c->af_fixed) &&
-                          (double)c->last_new <= c->decr_threshold * (double)c->col_words;
+                          (double)c->last_new <= (c->decr_threshold > 0 ? c->decr_threshold : c->decr_interleaved ? 0.5 : 0.2) *
+                                                     (double)c->col_words;
         for (i64 j = 0; j < n; ++j) {
             if (decr) TRY(enqueue_score_decr(c));
             else TRY(enqueue_score(c));
@@ -1088,7 +1170,9 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
             // once, read once), covered words rewritten, and one word per (selectable sample, listed word)
             const u64 entries = c->h_st->decr_entries - c->decr_entries_seen;
             const u64 gathers = c->h_st->decr_gathers - c->decr_gathers_seen;
-            c->algo_bytes += (i64)(passes * 2 * (i64)c->col_words * 8 + entries * 32 + gathers * 8);
+            // (interleaved copy: one word per (sample slot, listed word), selectable or not)
+            const u64 touched = c->decr_interleaved ? entries * interleaved_stride(c) : gathers;
+            c->algo_bytes += (i64)(passes * 2 * (i64)c->col_words * 8 + entries * 32 + touched * 8);
             c->decr_iterations += passes;
         }
         c->decr_entries_seen = c->h_st->decr_entries;
@@ -1193,6 +1277,7 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->n_chunks = (int32_t)c->chunks.size();
     out->decr_iterations = c->decr_iterations;
     out->brute_force_bytes = c->brute_bytes;
+    out->decr_interleaved_bytes = c->decr_interleaved ? (i64)(c->col_words * interleaved_stride(c) * 8) : 0;
     return UTM_OK;
 }
 
@@ -1200,7 +1285,7 @@ extern "C" int utm_set_decremental(utm_ctx *c, int32_t on, double threshold)
 {
     CTX(c);
     c->decr_enabled = on != 0;
-    c->decr_threshold = threshold > 0 ? threshold : 0.2;
+    c->decr_threshold = threshold > 0 ? threshold : 0;
     c->prepared = false;  // buffers are allocated at the next reset
     return UTM_OK;
 }
