@@ -131,6 +131,7 @@ def main():
         v0 += nv
     t_gen = time.perf_counter() - t_gen
     exchange = "none"
+    host_staged = False
     id_path = None
     transport = None
     if world > 1:
@@ -140,11 +141,23 @@ def main():
         # (or with --exchange rccl) the RCCL communicator carries the per-iteration exchange instead.
         from utmos_amd.sharded import bootstrap, enable_p2p
         transport, uid = bootstrap(rank, world, device.DeviceMatrix.comm_unique_id)
-        if args.exchange != "rccl":
+        if args.exchange != "rccl" and os.environ.get("UTM_NO_P2P", "0") == "0":
             enable_p2p(m, transport)
         if not m.fused_mailboxes:
-            m.comm_init(rank, world, uid)
+            try:
+                m.comm_init(rank, world, uid)
+                ok = 1
+            except device.nat.NativeError as e:
+                sys.stderr.write(f"bench.py rank {rank}: RCCL communicator unavailable ({e})\n")
+                ok = 0
+            oks = [r[1] for r in transport.allgather((0.0, ok, 0))]
+            if not all(oks):
+                if any(oks):
+                    raise SystemExit("bench.py: RCCL came up on some ranks only")
+                host_staged = True      # last resort: records and winner columns through the host sockets
         exchange = "device mailboxes + in-place column reads over hipIpc mappings (xGMI)" if m.fused_mailboxes else (
+            "host-staged: records over TCP, winner column " + ("read over hipIpc" if m.p2p else "through host memory")
+            if host_staged else
             "ncclAllGather of records, winner column read over hipIpc" if m.p2p else "ncclAllGather of records + columns")
     elif args.force_comm:
         uid, id_path = rendezvous_id(rank, world, device.DeviceMatrix.comm_unique_id)
@@ -165,6 +178,11 @@ def main():
 
     def one_step():
         m.reset()
+        if world > 1 and host_staged:
+            from utmos_amd.sharded import sharded_greedy
+            rows = list(sharded_greedy(m, transport, k_sel))
+            return (np.array([r[0] for r in rows], np.int64), np.array([r[1] for r in rows], np.int64),
+                    np.array([r[2] for r in rows], np.float64))
         return m.run(k_sel)
 
     for _ in range(args.warmup):

@@ -142,18 +142,23 @@ def test_cli_two_processes_sharded_over_samples(name, tmp_path):
     assert open(out).read() == ou.golden_text(CASES[name])
 
 
-def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("exchange", ["mailboxes", "host-staged"])
+def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path, exchange):
     """bench.py as the driver launches it for N > 1 (one process per rank, RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_* in the environment) -- here three ranks that all sit on the box's single GPU, small workload.
-    Rank 0 prints the one JSON line; the sharded rows equal its own single-GPU re-run."""
+    Rank 0 prints the one JSON line; the sharded rows equal its own single-GPU re-run.  Second case: no
+    hipIpc mappings (switched off) and no RCCL communicator (it refuses ranks that share a device) -- the
+    bench must still finish, on its host-staged last resort."""
     import json
     import subprocess
     import sys
-    port = 41500 + os.getpid() % 2000
+    port = 41500 + os.getpid() % 2000 + (0 if exchange == "mailboxes" else 2000)
     procs = []
     for rank in range(3):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), TMPDIR=str(tmp_path))
+        if exchange == "host-staged":
+            env["UTM_NO_P2P"] = "1"
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ou.ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
              "--n-var", "400000", "--n-samp", "301", "--no-cpu-baseline"],
@@ -164,7 +169,7 @@ def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path):
     line = json.loads(outs[0][0].strip().splitlines()[-1])
     assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["value"] > 0
     assert line["sharded_rows_match_single_gpu"] is True
-    assert "mailboxes" in line["config"]["sharding"]
+    assert exchange in line["config"]["sharding"]
     assert line["config"]["iterations_per_step"] == 301
 
 
