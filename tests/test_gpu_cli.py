@@ -105,10 +105,11 @@ def test_calculate_scores_drop_in(tmp_path):
         assert calculate_scores(m, mask) == (None, None)
 
 
-def _cli_rank(rank, world, port, argv, q):
+def _cli_rank(rank, world, port, argv, q, extra_env=None):
     import os
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port), "UTMOS_TRANSPORT": "socket"})
+    os.environ.update(extra_env or {})
     try:
         from utmos_amd.select import select_main
         select_main(argv + ["--device", "0"])
@@ -117,13 +118,18 @@ def _cli_rank(rank, world, port, argv, q):
         q.put((rank, repr(e)))
 
 
-@pytest.mark.parametrize("name", ["select_multi", "select_af", "select_weights_subset", "select_first:store"])
+@pytest.mark.parametrize("name", ["select_multi", "select_af", "select_weights_subset", "select_first:store",
+                                  "select_multi:no-p2p-no-rccl", "select_af:no-p2p-no-rccl"])
 def test_cli_two_processes_sharded_over_samples(name, tmp_path):
     """`utmos select` as one process per shard (here both on the box's single GPU; socket start-up, then the
-    device-side exchange): rank 0 writes the golden TSV.  `:store` = the shards load a packed .utm store."""
+    device-side exchange): rank 0 writes the golden TSV.  `:store` = the shards load a packed .utm store.
+    `:no-p2p-no-rccl` = mappings switched off and RCCL asked for, which refuses two ranks on one device: the
+    shards must agree on the host-staged exchange and still write the golden rows."""
     import multiprocessing as mp
     import os
-    name, _, from_store = name.partition(":")
+    name, _, variant = name.partition(":")
+    from_store = variant == "store"
+    extra_env = {"UTMOS_TRANSPORT": "rccl", "UTMOS_P2P": "0"} if variant == "no-p2p-no-rccl" else None
     argv, out = cli_args(CASES[name], tmp_path)
     if from_store:
         store = str(tmp_path / "m.utm")
@@ -132,7 +138,7 @@ def test_cli_two_processes_sharded_over_samples(name, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 35500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_cli_rank, args=(r, 2, port, argv, q)) for r in range(2)]
+    procs = [ctx.Process(target=_cli_rank, args=(r, 2, port, argv, q, extra_env)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)

@@ -391,7 +391,17 @@ def select_main(cmdargs):
         if os.environ.get("UTMOS_P2P", "1") == "1":
             enable_p2p(matrix, transport)           # hipIpc column mappings + record mailboxes, self-tested
         if not matrix.fused and not host_only:
-            matrix.comm_init(rank, world, uid)      # RCCL carries the per-iteration exchange instead
+            try:
+                matrix.comm_init(rank, world, uid)  # RCCL carries the per-iteration exchange instead
+                up = 1
+            except device.nat.NativeError as err:
+                logging.warning("no RCCL communicator on rank %d (%s)", rank, err)
+                up = 0
+            ups = [r[1] for r in transport.allgather((0.0, up, 0))]
+            if any(ups) and not all(ups):
+                logging.critical("RCCL came up on some shards only")
+                sys.exit(1)
+            # nowhere: the shards keep exchanging records (and, without mappings, columns) through the host sockets
         if matrix.fused:                            # the loop runs on the devices: nothing goes through the host
             transport.close()
             transport = None
