@@ -155,10 +155,13 @@ def main():
                 if any(oks):
                     raise SystemExit("bench.py: RCCL came up on some ranks only")
                 host_staged = True      # last resort: records and winner columns through the host sockets
-        exchange = "device mailboxes + in-place column reads over hipIpc mappings (xGMI)" if m.fused_mailboxes else (
-            "host-staged: records over TCP, winner column " + ("read over hipIpc" if m.p2p else "through host memory")
+        replica = m.stats()["p2p_replica_bytes"]
+        columns = (f"winner columns read from a one-time local copy of the other shards' columns ({replica / 1e9:.2f} GB)"
+                   if replica else "in-place column reads over hipIpc mappings (xGMI)")
+        exchange = f"device mailboxes + {columns}" if m.fused_mailboxes else (
+            "host-staged: records over TCP, winner column " + (columns if m.p2p else "through host memory")
             if host_staged else
-            "ncclAllGather of records, winner column read over hipIpc" if m.p2p else "ncclAllGather of records + columns")
+            f"ncclAllGather of records, {columns}" if m.p2p else "ncclAllGather of records + columns")
     elif args.force_comm:
         uid, id_path = rendezvous_id(rank, world, device.DeviceMatrix.comm_unique_id)
         m.comm_init(rank, world, uid)

@@ -75,6 +75,7 @@ typedef struct utm_stats {
     int32_t n_chunks;
     int64_t decr_iterations;   /* iterations scored decrementally (0 unless enabled) */
     int64_t brute_force_bytes; /* what full re-scoring of every iteration would have had to read */
+    int64_t p2p_replica_bytes; /* HBM holding copies of the other shards' columns (utm_p2p_import; 0: read in place) */
     int64_t decr_interleaved_bytes; /* HBM held by the word-interleaved copy the decremental iterations stream (0: gather form) */
 } utm_stats;
 

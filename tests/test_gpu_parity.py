@@ -380,6 +380,7 @@ def test_p2p_winner_columns_read_in_place_across_processes(dev):
 
 
 def _gpu_fused_worker(rank, world, port, q):
+    import os
     from utmos_amd.sharded import SocketTransport, enable_p2p, shard_bounds
     transport = SocketTransport(rank, world, port=port)
     try:
@@ -396,6 +397,7 @@ def _gpu_fused_worker(rank, world, port, q):
             m.synth_fill(c, seed=8)
             enable_p2p(m, transport)
             fused = m.fused
+            replica = m.stats()["p2p_replica_bytes"]
             for mode in ("int", "af32", "af64", "decr"):
                 m.set_af(c, None if mode in ("int", "decr") else (af if mode == "af32" else af.astype(np.float64) / 3.0))
                 m.set_decremental(mode == "decr", 1.0)
@@ -409,21 +411,25 @@ def _gpu_fused_worker(rank, world, port, q):
             a = None if mode in ("int", "decr") else (af if mode == "af32" else af.astype(np.float64) / 3.0)
             exp = ou.c_greedy(cols, n_var, state, w, af=a)
             ok = ok and got[0] == exp[0].tolist() and got[1] == exp[1].tolist() and got[2] == exp[2].tolist()
-        q.put((rank, ok, len(out["int"][0]), f"fused={fused}"))
+        ok = ok and (replica > 0) == (os.environ.get("UTM_P2P_REPLICATE", "1") != "0")
+        q.put((rank, ok, len(out["int"][0]), f"fused={fused} replica={replica}"))
     except BaseException as e:  # noqa: BLE001
         q.put((rank, False, 0, repr(e)))
     finally:
         transport.close()
 
 
-def test_fused_device_side_exchange_three_processes(dev):
+@pytest.mark.parametrize("columns", ["replicated", "in-place"])
+def test_fused_device_side_exchange_three_processes(dev, columns, monkeypatch):
     """The production multi-shard loop without RCCL in it: records through hipIpc-mapped mailboxes, winner
-    columns read in place, utm_run collective over three processes (sharing the box's one GPU)."""
+    columns read from the one-time local copy of the peers' columns (or in place through the mappings, what a
+    matrix too large to replicate runs), utm_run collective over three processes (sharing the box's one GPU)."""
     import multiprocessing as mp
     import os
+    monkeypatch.setenv("UTM_P2P_REPLICATE", "1" if columns == "replicated" else "0")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 39500 + os.getpid() % 2000
+    port = 39500 + os.getpid() % 2000 + (0 if columns == "replicated" else 2000)
     procs = [ctx.Process(target=_gpu_fused_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()

@@ -33,7 +33,7 @@ class Stats(ctypes.Structure):
                 ("af_mode", ctypes.c_int32), ("af_fixed_point", ctypes.c_int32),
                 ("af_q", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
                 ("decr_iterations", ctypes.c_int64), ("brute_force_bytes", ctypes.c_int64),
-                ("decr_interleaved_bytes", ctypes.c_int64)]
+                ("p2p_replica_bytes", ctypes.c_int64), ("decr_interleaved_bytes", ctypes.c_int64)]
 
 
 _P = ctypes.c_void_p

@@ -15,6 +15,13 @@ __global__ __launch_bounds__(256) void k_apply_pending(u64 *__restrict__ covered
         covered[w] |= __hip_atomic_load(&wcol[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// One-time copy of a peer shard's columns (hipIpc mapping, possibly across xGMI) into local memory.
+__global__ __launch_bounds__(256) void k_copy_remote(const u64 *__restrict__ src, u64 *__restrict__ dst, u64 words)
+{
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < words; w += (u64)gridDim.x * 256)
+        dst[w] = __hip_atomic_load(&src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // covered |= cols[col]  (utm_reset: samples that start out "used")
 __global__ __launch_bounds__(256) void k_or_column(u64 *__restrict__ covered, const u64 *__restrict__ col, u64 wp)
 {

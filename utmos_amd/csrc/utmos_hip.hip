@@ -102,6 +102,7 @@ struct Chunk {
     int index = 0;
     const u64 **d_peer_cols = nullptr;  // device array [n_ranks]: this chunk's column base on every rank (P2P), or null
     std::vector<void *> ipc_opened;     // mappings to close
+    u64 *replica = nullptr;             // the other shards' columns of this chunk, copied once (when there is room)
     u64 *mask = nullptr;           // AF delta scoring: per word, the bits the last winner newly covered
     unsigned *list_idx = nullptr;  // decremental scoring: words newly covered by the last winner
     u64 *list_val = nullptr;
@@ -175,6 +176,9 @@ struct utm_ctx {
     ncclComm_t comm = nullptr;
     // P2P: every rank maps every other rank's columns (hipIpc); the winner's column is then read in place
     bool p2p = false;
+    bool exported = false;               // peers map (and may have copied) the columns: they must not change any more
+    bool replicated = false;             // the peers' columns were copied into this GPU's memory: pending columns are local reads
+    u64 replica_bytes = 0;
     unsigned *d_peer_first = nullptr;  // [n_ranks]
     // record mailboxes (device-side exchange without a collective)
     Mailbox *d_mbox = nullptr;           // local slots [2][UTM_MAX_RANKS], uncached device memory, exported to the peers
@@ -206,7 +210,7 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
     p.chunk_off = ch.off;
     p.peer_cols = c->p2p ? (const u64 *const *)ch.d_peer_cols : nullptr;
     p.peer_first = c->d_peer_first;
-    p.fuse = scoring_kernel && !c->p2p;
+    p.fuse = scoring_kernel && (!c->p2p || c->replicated);  // a remote column is read once, by k_apply_pending
     return p;
 }
 
@@ -337,6 +341,7 @@ extern "C" int utm_upload_columns(utm_ctx *c, int32_t chunk, uint32_t first_col,
                                   const uint64_t *cols, uint64_t stride_words)
 {
     CTX(c);
+    if (c->exported) return fail(UTM_ESTATE, "the columns are exported to other shards (utm_p2p_export): fill them before exporting");
     Chunk *ch;
     TRY(chunk_of(c, chunk, &ch));
     if (!cols || (u64)first_col + n_cols > c->n_local || stride_words < ch->w)
@@ -369,6 +374,7 @@ extern "C" int utm_upload_rows_packed(utm_ctx *c, int32_t chunk, uint64_t first_
                                       const uint8_t *rows, uint64_t row_stride_bytes)
 {
     CTX(c);
+    if (c->exported) return fail(UTM_ESTATE, "the columns are exported to other shards (utm_p2p_export): fill them before exporting");
     Chunk *ch;
     TRY(chunk_of(c, chunk, &ch));
     if (!rows || n_rows == 0) return fail(UTM_EINVAL, "no rows");
@@ -420,6 +426,7 @@ extern "C" int utm_var_count(utm_ctx *c, int64_t *out)
 extern "C" int utm_synth_fill(utm_ctx *c, int32_t chunk, uint64_t seed, uint64_t first_var_global)
 {
     CTX(c);
+    if (c->exported) return fail(UTM_ESTATE, "the columns are exported to other shards (utm_p2p_export): fill them before exporting");
     Chunk *ch;
     TRY(chunk_of(c, chunk, &ch));
     const u64 blocks_per_col = (ch->w + 255) / 256;
@@ -526,7 +533,9 @@ extern "C" int utm_set_af(utm_ctx *c, int32_t chunk, int mode, const void *af)
         if (a == 0.0) { keep[v >> 6] &= ~(1ull << (v & 63)); any_zero = true; }
     }
     if (any_zero) {
+        if (c->exported) return fail(UTM_ESTATE, "the columns are exported to other shards (utm_p2p_export): set the AF before exporting");
         TRY(ensure_var_count(c));
+        ch->rows_t_valid = false;
         u64 *d_keep = nullptr;
         HIP_TRY(hipMalloc(&d_keep, ch->w * 8));
         HIP_TRY(copy_sync(c, d_keep, keep.data(), ch->w * 8, hipMemcpyHostToDevice));
@@ -971,7 +980,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
             const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
             const double af_switch = sw && *sw ? atof(sw) : 0.2;
             const bool af_dense = (double)c->captured_seen < af_switch * (double)c->n_var_total;
-            if (c->p2p) launch_apply_pending(c);
+            if (c->p2p && !c->replicated) launch_apply_pending(c);
             for (auto &ch : c->chunks) {
                 if (af_dense) launch_score_af_dense(c, ch, a_ub);
                 else launch_score_streaming(c, ch, a_ub);
@@ -984,7 +993,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
             for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub, /*delta=*/true);
         }
     } else {
-        if (c->p2p) launch_apply_pending(c);  // the scoring kernels do not fuse the update here: read the winner's column once
+        if (c->p2p && !c->replicated) launch_apply_pending(c);  // remote column: read it once, not once per workgroup
         for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub);
     }
     HIP_TRY(hipGetLastError());
@@ -1277,6 +1286,7 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->n_chunks = (int32_t)c->chunks.size();
     out->decr_iterations = c->decr_iterations;
     out->brute_force_bytes = c->brute_bytes;
+    out->p2p_replica_bytes = (i64)c->replica_bytes;
     out->decr_interleaved_bytes = c->decr_interleaved ? (i64)(c->col_words * interleaved_stride(c) * 8) : 0;
     return UTM_OK;
 }
@@ -1423,6 +1433,7 @@ extern "C" int utm_p2p_export(utm_ctx *c, void *blob)
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
     }
+    c->exported = true;
     P2PHeader hd{c->first, c->n_local, (uint32_t)c->chunks.size(), c->d_mbox ? 1u : 0u};
     memcpy(blob, &hd, sizeof hd);
     hipIpcMemHandle_t *hs = reinterpret_cast<hipIpcMemHandle_t *>(static_cast<char *>(blob) + sizeof hd);
@@ -1443,7 +1454,11 @@ static void p2p_close(utm_ctx *c)
         ch.ipc_opened.clear();
         (void)hipFree(ch.d_peer_cols);
         ch.d_peer_cols = nullptr;
+        (void)hipFree(ch.replica);
+        ch.replica = nullptr;
     }
+    c->replicated = false;
+    c->replica_bytes = 0;
     (void)hipFree(c->d_peer_first);
     c->d_peer_first = nullptr;
     for (void *p : c->mbox_opened) (void)hipIpcCloseMemHandle(p);
@@ -1463,7 +1478,7 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
     const size_t blob = sizeof(P2PHeader) + (c->chunks.size() + 1) * sizeof(hipIpcMemHandle_t);
     std::vector<Mailbox *> boxes(n_ranks, nullptr);
     bool all_boxes = c->d_mbox != nullptr;
-    std::vector<unsigned> firsts(n_ranks);
+    std::vector<unsigned> firsts(n_ranks), locals(n_ranks);
     std::vector<std::vector<const u64 *>> table(c->chunks.size(), std::vector<const u64 *>(n_ranks, nullptr));
     for (int r = 0; r < n_ranks; ++r) {
         const char *b = static_cast<const char *>(blobs) + (size_t)r * blob;
@@ -1471,6 +1486,7 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
         memcpy(&hd, b, sizeof hd);
         if (hd.n_chunks != c->chunks.size()) { p2p_close(c); return fail(UTM_EINVAL, "rank %d has %u chunks, this one %zu", r, hd.n_chunks, c->chunks.size()); }
         firsts[r] = hd.first;
+        locals[r] = hd.n_local;
         const hipIpcMemHandle_t *hs = reinterpret_cast<const hipIpcMemHandle_t *>(b + sizeof hd);
         for (size_t k = 0; k < c->chunks.size(); ++k) {
             if (r == rank) { table[k][r] = c->chunks[k].cols; continue; }
@@ -1493,6 +1509,41 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
             }
         } else {
             all_boxes = false;
+        }
+    }
+    // Room permitting, copy the peers' columns over once (xGMI, the same system-scope reads the loop would do per
+    // iteration) and resolve pending columns in local memory from then on: at 10M variants a winner's column is
+    // 1.25 MB, ~20 us over one link, every iteration -- against a 3.1 GB one-time copy.  Columns are static after
+    // the export; matrices that do not fit (cfg4: 78 GB per shard) keep the in-place reads, where the scan dominates.
+    {
+        u64 need = 0;
+        for (int r = 0; r < n_ranks; ++r)
+            if (r != rank) need += (u64)locals[r] * c->col_words * 8;
+        size_t free_b = 0, total_b = 0;
+        const char *env = getenv("UTM_P2P_REPLICATE");
+        const bool wanted = n_ranks > 1 && !(env && *env == '0');
+        if (wanted && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (u64)free_b > need + (8ull << 30)) {
+            bool ok = true;
+            for (size_t k = 0; k < c->chunks.size() && ok; ++k) {
+                Chunk &ch = c->chunks[k];
+                ok = hipMalloc(&ch.replica, (size_t)(need / c->col_words * ch.wp)) == hipSuccess;
+                u64 off = 0;
+                for (int r = 0; r < n_ranks && ok; ++r) {
+                    if (r == rank) continue;
+                    const u64 words = (u64)locals[r] * ch.wp;
+                    hipLaunchKernelGGL(k_copy_remote, dim3(2048), dim3(256), 0, c->stream, table[k][r], ch.replica + off, words);
+                    table[k][r] = ch.replica + off;
+                    off += words;
+                }
+            }
+            if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
+            if (!ok) {
+                (void)hipGetLastError();
+                p2p_close(c);
+                return fail(UTM_EHIP, "copying the peers' columns failed");
+            }
+            c->replicated = true;
+            c->replica_bytes = need;
         }
     }
     HIP_TRY(hipMalloc(&c->d_peer_first, (size_t)n_ranks * 4));
