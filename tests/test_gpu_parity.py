@@ -489,7 +489,7 @@ def test_decremental_scoring_gives_the_same_rows(dev, mode, layout, monkeypatch)
     """later iterations only subtract what the last winner newly covered; same rows, and the
     device really ran decremental iterations -- streaming the word-interleaved copy, or gathering from the
     columns (what a context without room for the copy runs)."""
-    monkeypatch.setenv("UTM_DECR_INTERLEAVED", "1" if layout == "interleaved" else "0")
+    monkeypatch.setenv("UTM_DECR_INTERLEAVED", "0" if layout == "gather" else "1")
     rng = np.random.default_rng(30)
     n_var, n_samp = 64 * 128 * 6 + 99, 150
     dense = ou.random_dense(rng, n_var, n_samp)
@@ -507,7 +507,7 @@ def test_decremental_scoring_gives_the_same_rows(dev, mode, layout, monkeypatch)
     _, stats = check_run(dev, dense, state=state, decremental=1.0, **kw)   # threshold 1.0: decremental from the 2nd batch on
     assert stats["decr_iterations"] > 0
     assert stats["algo_bytes"] < stats["brute_force_bytes"]
-    assert (stats["decr_interleaved_bytes"] > 0) == (layout == "interleaved")
+    assert (stats["decr_interleaved_bytes"] > 0) == (layout != "gather")
 
 
 def test_decremental_survives_peek_and_covered_reads(dev):

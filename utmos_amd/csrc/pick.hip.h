@@ -65,6 +65,39 @@ __device__ void decide(const PickArgs &a)
     if (st->tot >= a.n_var_total) st->done = 1;  // "Ran out of new variants" (select.py:110-112)
 }
 
+// The same decision for the only shard (MODE 0), on values thread 0 loaded while the scan was in flight: nothing
+// but stores are left on the critical path.
+struct Preloaded {
+    i64 iter, tot, n_active_total;
+    unsigned last_act;  // act[n_active - 1]: moves into the winner's position
+};
+__device__ __forceinline__ void decide_single(const PickArgs &a, const Cand &best, unsigned n_active, const Preloaded &p)
+{
+    IterState *st = a.st;
+    const i64 k = p.iter;
+    const bool zero_elsewhere = p.n_active_total < (i64)a.n_total;
+    if (n_active == 0 || best.val == 0.0 || (best.val < 0.0 && zero_elsewhere)) {
+        st->done = 1;
+        a.res_idx[k] = -1;
+        return;
+    }
+    a.res_idx[k] = best.gidx;
+    a.res_new[k] = best.cnt;
+    a.res_score[k] = best.val;
+    st->iter = k + 1;
+    st->tot = p.tot + best.cnt;
+    st->n_active_total = p.n_active_total - 1;
+    st->prev_valid = 1;
+    st->prev_rank = 0;
+    st->prev_gidx = best.gidx;
+    const unsigned loc = (unsigned)(best.gidx - a.first);
+    a.state[loc] = 0;
+    a.act[best.pos] = p.last_act;
+    st->n_active = n_active - 1;
+    st->prev_local = (int)loc;
+    if (p.tot + best.cnt >= a.n_var_total) st->done = 1;
+}
+
 // Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
 // landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
 #define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
@@ -95,6 +128,13 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
     IterState *st = a.st;
     if (st->done) return;
     const unsigned n_active = st->n_active;
+    Preloaded pre{0, 0, 0, 0};
+    if (MODE == 0 && threadIdx.x == 0) {
+        pre.iter = st->iter;
+        pre.tot = st->tot;
+        pre.n_active_total = st->n_active_total;
+        pre.last_act = n_active ? a.act[n_active - 1] : 0;
+    }
     // where this iteration's scores come from
     //   0 integer counts | 1 exact fixed-point AF sums | 2 sequential float64 scores of every sample
     //   3 the candidates' sequential float64 scores (k_chain)
@@ -159,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
             st->decr_entries += n_l;
             st->decr_gathers += n_l * n_active;
         }
-        if (MODE == 0) decide(a);
+        if (MODE == 0) decide_single(a, best, n_active, pre);
     }
     if (MODE == 2) {
         __syncthreads();
