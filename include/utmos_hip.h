@@ -82,6 +82,8 @@ typedef struct utm_stats {
 const char *utm_last_error(void);
 int utm_abi_version(void);
 int utm_device_count(int *n);
+/* Free and total HBM of a device in bytes (hipMemGetInfo): what the host's is_memsafe policy (select.py:56-63) asks. */
+int utm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* ---- context ------------------------------------------------------------------------------ */
 int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_sample, uint32_t n_samp_local,

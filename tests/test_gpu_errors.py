@@ -1,0 +1,159 @@
+"""GPU: error behaviour and lifecycle of the C ABI.  The reference raises nothing on this path and signals
+exhaustion by (None, None) / generator return (select.py:51-52, :96, :112); everything the boundary adds --
+argument checks, state checks, device memory ownership -- is pinned here."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from oracle_util import npo
+
+pytestmark = pytest.mark.gpu
+
+EINVAL, ESTATE = -1, -4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from utmos_amd import _native as nat
+    assert nat.device_count() >= 1, "no GPU visible"
+    from utmos_amd import device
+    return device
+
+
+def code_of(excinfo):
+    return excinfo.value.code
+
+
+def test_create_rejects_bad_shapes_and_devices(dev):
+    nat = dev.nat
+    for args in ((0, 0, 0), (8, 4, 8), (8, 0, 9)):                 # no samples / shard beyond the end / shard too long
+        h = ctypes.c_void_p()
+        rc = nat.lib().utm_ctx_create(0, args[0], args[1], args[2], 0, ctypes.byref(h))
+        assert rc == EINVAL and not h.value, args
+        assert nat.lib().utm_last_error()
+    h = ctypes.c_void_p()
+    assert nat.lib().utm_ctx_create(nat.device_count(), 8, 0, 8, 0, ctypes.byref(h)) != 0    # no such device
+    assert nat.lib().utm_ctx_create(0, 8, 0, 8, 0, None) == EINVAL
+    assert nat.lib().utm_ctx_destroy(None) in (0, EINVAL)       # harmless either way
+
+
+def test_argument_checks_leave_the_context_usable(dev):
+    rng = np.random.default_rng(3)
+    n_var, n_samp = 3000, 20
+    dense = ou.random_dense(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8))
+    with dev.DeviceMatrix(n_samp) as m:
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.run(3)                                        # nothing loaded yet
+        assert code_of(e) in (EINVAL, ESTATE)
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.add_chunk(0)
+        assert code_of(e) == EINVAL
+        c = m.add_chunk(n_var)
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.upload_columns(c, cols[:, :10])               # stride shorter than the chunk's words
+        assert code_of(e) == EINVAL
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.upload_columns(c, cols, first_col=5)          # runs past the last column
+        assert code_of(e) == EINVAL
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.upload_columns(c + 1, cols)                   # no such chunk
+        assert code_of(e) == EINVAL
+        m.upload_columns(c, cols)
+        bad_state = np.ones(n_samp, np.uint8)
+        bad_state[3] = 3
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.set_state(bad_state)
+        assert code_of(e) == EINVAL
+        for bad in (np.nan, np.inf):
+            w = np.ones(n_samp)
+            w[2] = bad
+            with pytest.raises(dev.nat.NativeError) as e:   # deviation from the reference (NaN would propagate): refused
+                m.set_weights(w)
+            assert code_of(e) == EINVAL
+            af = np.full(n_var, 0.25)
+            af[7] = bad
+            with pytest.raises(dev.nat.NativeError) as e:
+                m.set_af(c, af)
+            assert code_of(e) == EINVAL
+        af = np.full(n_var, 0.25, np.float32)
+        af[9] = -0.5
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.set_af(c, af)
+        assert code_of(e) == EINVAL
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.run(-1)
+        assert code_of(e) == EINVAL
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.get_column(n_samp)                            # not a sample of this context
+        assert code_of(e) == EINVAL
+        # none of the refused calls left anything behind
+        got = m.run(n_samp)
+        assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+        # asking for more rows than there are samples is not an error: the loop just ends
+        m.reset()
+        got = m.run(10 * n_samp)
+        assert got[0].tolist() == exp[0].tolist()
+
+
+def test_columns_are_frozen_once_exported_to_other_shards(dev):
+    """Peers map (and may copy) an exported shard's columns: later changes are refused, not silently missed."""
+    rng = np.random.default_rng(4)
+    n_var, n_samp = 2000, 12
+    cols = npo.pack_columns(ou.random_dense(rng, n_var, n_samp))
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols)
+        m.set_af(c, np.full(n_var, 0.5, np.float32))        # before the export: fine
+        m.p2p_export()
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.upload_columns(c, cols)
+        assert code_of(e) == ESTATE
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.synth_fill(c, seed=1)
+        assert code_of(e) == ESTATE
+        af = np.full(n_var, 0.5, np.float32)
+        af[0] = 0.0                                          # would clear a row of the exported columns
+        with pytest.raises(dev.nat.NativeError) as e:
+            m.set_af(c, af)
+        assert code_of(e) == ESTATE
+        m.set_af(c, np.full(n_var, 0.25, np.float32))       # values only: allowed
+
+
+def test_contexts_give_their_device_memory_back(dev):
+    """Create / fill / run / destroy in every mode, repeatedly: free HBM returns to where it was."""
+    nat = dev.nat
+    rng = np.random.default_rng(5)
+    n_var, n_samp = 64 * 128 * 40, 96                       # 40 KiB columns
+    dense = ou.random_dense(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    af = (dense.sum(axis=1) / (2.0 * n_samp))
+
+    def cycle(mode):
+        with dev.DeviceMatrix(n_samp) as m:
+            c = m.add_chunk(n_var)
+            m.upload_columns(c, cols)
+            if mode == "af32":
+                m.set_af(c, af.astype(np.float32))
+            if mode == "af64":
+                m.set_af(c, af / 3.0)
+            if mode == "decr":
+                m.set_decremental(True, 1.0)
+            if mode == "p2p":
+                m.p2p_import(0, [m.p2p_export()])
+            m.run(20)
+            m.peek_scores()
+            m.var_count()
+
+    for mode in ("int", "af32", "af64", "decr", "p2p"):      # first round: lazy one-time allocations of the runtime
+        cycle(mode)
+    free0, total = nat.device_memory(0)
+    assert 0 < free0 <= total
+    for _ in range(6):
+        for mode in ("int", "af32", "af64", "decr", "p2p"):
+            cycle(mode)
+    free1, _ = nat.device_memory(0)
+    assert free0 - free1 < 64 << 20, (free0, free1)           # nothing near 30 contexts' worth (each > 4 MB) is missing

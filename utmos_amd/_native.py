@@ -43,6 +43,7 @@ _U64, _U32, _I32, _I64 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctype
 PROTOTYPES = {
     "utm_abi_version": [],
     "utm_device_count": [ctypes.POINTER(ctypes.c_int)],
+    "utm_device_memory": [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
     "utm_ctx_create": [ctypes.c_int, _U32, _U32, _U32, _U32, ctypes.POINTER(_P)],
     "utm_ctx_destroy": [_P],
     "utm_add_chunk": [_P, _U64, ctypes.POINTER(_I32)],
@@ -113,3 +114,10 @@ def device_count():
     n = ctypes.c_int(0)
     check(lib().utm_device_count(ctypes.byref(n)))
     return n.value
+
+
+def device_memory(device=0):
+    """(free, total) HBM bytes of a device."""
+    free, total = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(lib().utm_device_memory(int(device), ctypes.byref(free), ctypes.byref(total)))
+    return free.value, total.value

@@ -50,6 +50,20 @@ extern "C" int utm_device_count(int *n)
     return UTM_OK;
 }
 
+extern "C" int utm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes)
+{
+    if (!free_bytes || !total_bytes) return fail(UTM_EINVAL, "output is NULL");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(UTM_EINVAL, "device %d of %d", device, n);
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = f;
+    *total_bytes = t;
+    return UTM_OK;
+}
+
 // ---------------------------------------------------------------------------------------- RCCL (lazy)
 // librccl is loaded on first use so that single-GPU runs do not depend on it.
 struct Rccl {
@@ -1139,7 +1153,10 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     const i64 room = (i64)c->n_total - iter0;
     if (k_max > room) k_max = room;
     HIP_TRY(hipEventRecord(c->ev_loop0, c->stream));
-    static const int batch = std::max(1, tune_env("UTM_BATCH", 64));
+    // iterations enqueued between two host syncs: AF modes latch host-side decisions there (64); the integer loop
+    // only needs the stop flag (256: a boundary costs an idle device for two round trips)
+    static const int batch_env = tune_env("UTM_BATCH", 0);
+    const int batch = batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
     i64 enq = 0;
     while (enq < k_max && !c->finished) {
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
