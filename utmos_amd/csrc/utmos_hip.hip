@@ -940,8 +940,14 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
 {
     static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
     static const int min_wgs = tune_env("UTM_MIN_WGS", 1024);
+    static const int min_wgs_big = tune_env("UTM_MIN_WGS_BIG", 8192);  // the 32 KiB tile wants a deeper grid (chr22-sized: +17 % with 8 KiB)
     static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
-    static const int use_nt = tune_env("UTM_NT_LOADS", 1);
+    static const int nt_env = tune_env("UTM_NT_LOADS", -1);
+    static const int nt_min_mb = tune_env("UTM_NT_MIN_MB", 512);
+    // non-temporal column loads when the matrix is a stream far larger than the 256 MB Infinity Cache (+10 % at
+    // 3 GB); a matrix that (nearly) fits is better left to the caches (chr22-sized 345 MB: +5 %).  By the matrix, not
+    // by the columns still selectable: the tail of a 3 GB select-all run measured slower with cached loads.
+    const bool use_nt = nt_env >= 0 ? nt_env != 0 : (u64)c->n_local * c->col_words * 8 > ((u64)nt_min_mb << 20);
     static const int af_big = tune_env("UTM_AF_STEPS", 16) == 32 ? 32 : 16;
     const bool af = c->af_mode != UTM_AF_NONE;
     const u64 steps_total = ch.wp / UTM_STEP_WORDS;
@@ -949,7 +955,7 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
     int steps = 2;
     for (int cand : {af ? af_big : 32, 8}) {  // (the AF kernel shares LDS with its bit queues)
         const u64 tiles = (steps_total + cand - 1) / cand;
-        if (tiles * waves_needed >= (u64)min_wgs) { steps = cand; break; }
+        if (tiles * waves_needed >= (u64)(cand > 8 ? min_wgs_big : min_wgs)) { steps = cand; break; }
     }
     if (!af && (force_steps == 32 || force_steps == 16 || force_steps == 8 || force_steps == 2)) steps = force_steps;
     const u64 tiles = (steps_total + steps - 1) / steps;
