@@ -29,8 +29,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--n-var", type=int, default=10_000_000)
     p.add_argument("--n-samp", type=int, default=2504)
     p.add_argument("--select", type=int, default=-1, help="samples to select per step (-1 = all)")

@@ -7,6 +7,7 @@
 #include "../../include/utmos_hip.h"
 
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 #include <rccl/rccl.h>
 #include <stdarg.h>
@@ -861,24 +862,15 @@ static int tune_env(const char *name, int dflt)
     return v && *v ? atoi(v) : dflt;
 }
 
-template <int STEPS>
-static void launch_score_int(utm_ctx *c, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups, bool nt)
-{
-    if (nt)
-        hipLaunchKernelGGL((k_score_int<STEPS, true>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                           pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
-    else
-        hipLaunchKernelGGL((k_score_int<STEPS, false>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                           pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, group, n_groups);
-}
-
-// HIP-event bracket around one scoring launch (UTM_FLAG_PROFILE_EVENTS); a no-op otherwise.
+// Start / stop events of ONE scoring dispatch (UTM_FLAG_PROFILE_EVENTS): handed to hipExtLaunchKernelGGL, which
+// stamps them from the dispatch itself -- the kernel's own duration, as a kernel trace reports it (events recorded
+// around the launch add ~5 us of bracket to every measurement).  Null events = a plain launch.
 struct LaunchTimer {
-    utm_ctx *c;
-    bool on;
-    explicit LaunchTimer(utm_ctx *ctx) : c(ctx), on(ctx->flags & UTM_FLAG_PROFILE_EVENTS)
+    hipEvent_t start = nullptr, stop = nullptr;
+    explicit LaunchTimer(utm_ctx *c)
     {
-        if (!on) return;
+        c->score_launches += 1;
+        if (!(c->flags & UTM_FLAG_PROFILE_EVENTS)) return;
         if (c->ev_used + 2 > c->ev.size()) {
             hipEvent_t a, b;
             (void)hipEventCreate(&a);
@@ -886,16 +878,26 @@ struct LaunchTimer {
             c->ev.push_back(a);
             c->ev.push_back(b);
         }
-        (void)hipEventRecord(c->ev[c->ev_used], c->stream);
-    }
-    ~LaunchTimer()
-    {
-        c->score_launches += 1;
-        if (!on) return;
-        (void)hipEventRecord(c->ev[c->ev_used + 1], c->stream);
+        start = c->ev[c->ev_used];
+        stop = c->ev[c->ev_used + 1];
         c->ev_used += 2;
     }
 };
+#define UTM_TIMED_LAUNCH(timer, kernel, grid, block, ...) \
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, (timer).start, (timer).stop, 0, __VA_ARGS__)
+
+template <int STEPS>
+static void launch_score_int(utm_ctx *c, const LaunchTimer &t, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups,
+                             bool nt)
+{
+    const u64 *cols = ch.cols;
+    if (nt)
+        UTM_TIMED_LAUNCH(t, (k_score_int<STEPS, true>), dim3(blocks), dim3(256), cols, ch.covered, ch.wp, pending_of(c, ch, true),
+                         (const IterState *)c->d_st, (const unsigned *)c->d_act, c->d_cnt, group, n_groups);
+    else
+        UTM_TIMED_LAUNCH(t, (k_score_int<STEPS, false>), dim3(blocks), dim3(256), cols, ch.covered, ch.wp, pending_of(c, ch, true),
+                         (const IterState *)c->d_st, (const unsigned *)c->d_act, c->d_cnt, group, n_groups);
+}
 
 static void launch_apply_pending(utm_ctx *c)
 {
@@ -912,11 +914,11 @@ static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
     LaunchTimer t(c);
     const unsigned blocks = (a_ub + 63) / 64;
     if (c->af_mode == UTM_AF_F32)
-        hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                           c->d_act, c->d_cnt, c->d_fscore, 0);
+        hipExtLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, t.start, t.stop, 0, c->d_seq,
+                              (int)c->chunks.size(), c->d_st, c->d_act, c->d_cnt, c->d_fscore, 0);
     else
-        hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                           c->d_act, c->d_cnt, c->d_fscore, 0);
+        hipExtLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, t.start, t.stop, 0, c->d_seq,
+                              (int)c->chunks.size(), c->d_st, c->d_act, c->d_cnt, c->d_fscore, 0);
 }
 
 // AF, dense phase: LDS AF tiles.  Every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache), so
@@ -929,8 +931,9 @@ static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
     const unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
     n_groups = (a_ub + group - 1) / group;
     LaunchTimer t(c);
-    hipLaunchKernelGGL(k_score_afq, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp,
-                       ch.af32, 150 - c->af_q, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, group, n_groups);
+    hipExtLaunchKernelGGL(k_score_afq, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,
+                          ch.covered, ch.wp, ch.af32, 150 - c->af_q, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,
+                          group, n_groups);
 }
 
 // The streaming kernels (k_score_int, k_score_afs): grid = variant tiles x groups of samples.  Tile = the largest
@@ -968,18 +971,18 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
         const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
         const int eb = 150 - c->af_q;
 #define UTM_LAUNCH_AFS(S, Q)                                                                                              \
-    hipLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, ch.cols, ch.covered, ch.wp, afb, eb,   \
-                       pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, (unsigned)group, n_groups,        \
-                       delta ? ch.mask : nullptr)
+    hipExtLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,       \
+                          ch.covered, ch.wp, afb, eb, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,   \
+                          (unsigned)group, n_groups, delta ? ch.mask : nullptr)
         if (steps == 32) UTM_LAUNCH_AFS(32, 8);  // second argument: queue depth per lane
         else if (steps == 16) UTM_LAUNCH_AFS(16, 16);
         else if (steps == 8) UTM_LAUNCH_AFS(8, 16);
         else UTM_LAUNCH_AFS(2, 16);
 #undef UTM_LAUNCH_AFS
-    } else if (steps == 32) launch_score_int<32>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
-    else if (steps == 16) launch_score_int<16>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
-    else if (steps == 8) launch_score_int<8>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
-    else launch_score_int<2>(c, ch, blocks, (unsigned)group, n_groups, use_nt);
+    } else if (steps == 32) launch_score_int<32>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else if (steps == 16) launch_score_int<16>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else if (steps == 8) launch_score_int<8>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else launch_score_int<2>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
 }
 
 // Enqueue the scoring of one iteration for every chunk (and the pending covered update).
