@@ -1,0 +1,489 @@
+// One greedy iteration as kernel launches, and the entry points that run them: utm_run / utm_step / utm_peek_scores / stats.
+// Part of the one translation unit utmos_hip.hip (included there, in order); not a stand-alone header.
+#pragma once
+
+// ---------------------------------------------------------------------------------------- launches
+static int tune_env(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// Start / stop events of ONE scoring dispatch (UTM_FLAG_PROFILE_EVENTS): handed to hipExtLaunchKernelGGL, which
+// stamps them from the dispatch itself -- the kernel's own duration, as a kernel trace reports it (events recorded
+// around the launch add ~5 us of bracket to every measurement).  Null events = a plain launch.
+struct LaunchTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    explicit LaunchTimer(utm_ctx *c)
+    {
+        c->score_launches += 1;
+        if (!(c->flags & UTM_FLAG_PROFILE_EVENTS)) return;
+        if (c->ev_used + 2 > c->ev.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            c->ev.push_back(a);
+            c->ev.push_back(b);
+        }
+        start = c->ev[c->ev_used];
+        stop = c->ev[c->ev_used + 1];
+        c->ev_used += 2;
+    }
+};
+#define UTM_TIMED_LAUNCH(timer, kernel, grid, block, ...) \
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, (timer).start, (timer).stop, 0, __VA_ARGS__)
+
+template <int STEPS>
+static void launch_score_int(utm_ctx *c, const LaunchTimer &t, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups,
+                             bool nt)
+{
+    const u64 *cols = ch.cols;
+    if (nt)
+        UTM_TIMED_LAUNCH(t, (k_score_int<STEPS, true>), dim3(blocks), dim3(256), cols, ch.covered, ch.wp, pending_of(c, ch, true),
+                         (const IterState *)c->d_st, (const unsigned *)c->d_act, c->d_cnt, group, n_groups);
+    else
+        UTM_TIMED_LAUNCH(t, (k_score_int<STEPS, false>), dim3(blocks), dim3(256), cols, ch.covered, ch.wp, pending_of(c, ch, true),
+                         (const IterState *)c->d_st, (const unsigned *)c->d_act, c->d_cnt, group, n_groups);
+}
+
+static void launch_apply_pending(utm_ctx *c)
+{
+    for (auto &ch : c->chunks)
+        hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                           ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
+}
+
+// Sequential AF scoring of every selectable sample: covered is brought up to date first, then one lane per
+// sample walks all chunks in order.
+static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
+{
+    launch_apply_pending(c);
+    LaunchTimer t(c);
+    const unsigned blocks = (a_ub + 63) / 64;
+    if (c->af_mode == UTM_AF_F32)
+        hipExtLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, t.start, t.stop, 0, c->d_seq,
+                              (int)c->chunks.size(), c->d_st, c->d_act, c->d_cnt, c->d_fscore, 0);
+    else
+        hipExtLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, t.start, t.stop, 0, c->d_seq,
+                              (int)c->chunks.size(), c->d_st, c->d_act, c->d_cnt, c->d_fscore, 0);
+}
+
+// AF, dense phase: LDS AF tiles.  Every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache), so
+// the groups hold >= 64 samples.
+static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
+{
+    static const int af_target = tune_env("UTM_AF_TARGET_WGS", 16384);
+    const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
+    unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)af_target / std::max<u64>(1, tiles)));
+    const unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
+    n_groups = (a_ub + group - 1) / group;
+    LaunchTimer t(c);
+    hipExtLaunchKernelGGL(k_score_afq, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,
+                          ch.covered, ch.wp, ch.af32, 150 - c->af_q, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,
+                          group, n_groups);
+}
+
+// The streaming kernels (k_score_int, k_score_afs): grid = variant tiles x groups of samples.  Tile = the largest
+// of {32 (AF: 16), 8, 2} KiB that still yields >= UTM_MIN_WGS workgroups; group size such that the grid has about
+// UTM_TARGET_WGS workgroups (>> 256 CUs, small enough units for an even tail), at least one sample per wave.
+static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta = false)
+{
+    static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
+    static const int min_wgs = tune_env("UTM_MIN_WGS", 1024);
+    static const int min_wgs_big = tune_env("UTM_MIN_WGS_BIG", 8192);  // the 32 KiB tile wants a deeper grid (chr22-sized: +17 % with 8 KiB)
+    static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
+    static const int nt_env = tune_env("UTM_NT_LOADS", -1);
+    static const int nt_min_mb = tune_env("UTM_NT_MIN_MB", 512);
+    // non-temporal column loads when the matrix is a stream far larger than the 256 MB Infinity Cache (+10 % at
+    // 3 GB); a matrix that (nearly) fits is better left to the caches (chr22-sized 345 MB: +5 %).  By the matrix, not
+    // by the columns still selectable: the tail of a 3 GB select-all run measured slower with cached loads.
+    const bool use_nt = nt_env >= 0 ? nt_env != 0 : (u64)c->n_local * c->col_words * 8 > ((u64)nt_min_mb << 20);
+    static const int af_big = tune_env("UTM_AF_STEPS", 16) == 32 ? 32 : 16;
+    const bool af = c->af_mode != UTM_AF_NONE;
+    const u64 steps_total = ch.wp / UTM_STEP_WORDS;
+    const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
+    int steps = 2;
+    for (int cand : {af ? af_big : 32, 8}) {  // (the AF kernel shares LDS with its bit queues)
+        const u64 tiles = (steps_total + cand - 1) / cand;
+        if (tiles * waves_needed >= (u64)(cand > 8 ? min_wgs_big : min_wgs)) { steps = cand; break; }
+    }
+    if (!af && (force_steps == 32 || force_steps == 16 || force_steps == 8 || force_steps == 2)) steps = force_steps;
+    const u64 tiles = (steps_total + steps - 1) / steps;
+    u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
+    group = std::max<u64>(4, (group + 3) / 4 * 4);
+    const unsigned n_groups = (unsigned)((a_ub + group - 1) / group);
+    const unsigned blocks = (unsigned)round_up(tiles * n_groups, 8);  // XCD-aware map: tile_of_block()
+    LaunchTimer t(c);
+    if (af) {
+        const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
+        const int eb = 150 - c->af_q;
+#define UTM_LAUNCH_AFS(S, Q)                                                                                              \
+    hipExtLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,       \
+                          ch.covered, ch.wp, afb, eb, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,   \
+                          (unsigned)group, n_groups, delta ? ch.mask : nullptr)
+        if (steps == 32) UTM_LAUNCH_AFS(32, 8);  // second argument: queue depth per lane
+        else if (steps == 16) UTM_LAUNCH_AFS(16, 16);
+        else if (steps == 8) UTM_LAUNCH_AFS(8, 16);
+        else UTM_LAUNCH_AFS(2, 16);
+#undef UTM_LAUNCH_AFS
+    } else if (steps == 32) launch_score_int<32>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else if (steps == 16) launch_score_int<16>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else if (steps == 8) launch_score_int<8>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
+    else launch_score_int<2>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
+}
+
+// Enqueue the scoring of one iteration for every chunk (and the pending covered update).
+static int enqueue_score(utm_ctx *c, bool force_sequential = false)
+{
+    const unsigned a_ub = std::max(1u, c->active_ub);
+    if (c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential)) {
+        launch_score_sequential(c, a_ub);
+    } else if (c->af_mode != UTM_AF_NONE) {
+        // AF, verified-parallel: persistent accumulators.  Without valid accumulators: clear them and run a full
+        // pass (dense phase -> LDS-tile kernel, else the streaming kernel).  Otherwise a *delta* pass: the mask of
+        // variants the last winner newly covered is made once (k_newly_mask, which also updates covered, from a
+        // local or a peer-mapped column) and the streaming kernel subtracts those variants' share -- same bytes
+        // streamed, but only the newly covered bits take the queue / gather path.
+        if (!c->keep_valid) {
+            HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream));
+            HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
+            const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
+            const double af_switch = sw && *sw ? atof(sw) : 0.2;
+            const bool af_dense = (double)c->captured_seen < af_switch * (double)c->n_var_total;
+            if (c->p2p && !c->replicated) launch_apply_pending(c);
+            for (auto &ch : c->chunks) {
+                if (af_dense) launch_score_af_dense(c, ch, a_ub);
+                else launch_score_streaming(c, ch, a_ub);
+            }
+            c->keep_valid = true;
+        } else {
+            for (auto &ch : c->chunks)
+                hipLaunchKernelGGL(k_newly_mask, dim3((unsigned)std::min<u64>(2048, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                                   ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, ch.mask);
+            for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub, /*delta=*/true);
+        }
+    } else {
+        if (c->p2p && !c->replicated) launch_apply_pending(c);  // remote column: read it once, not once per workgroup
+        for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub);
+    }
+    HIP_TRY(hipGetLastError());
+    return UTM_OK;
+}
+
+// Decremental scoring of one iteration: list the words the pending winner newly covers, subtract.
+static int enqueue_score_decr(utm_ctx *c)
+{
+    const unsigned a_ub = std::max(1u, c->active_ub);
+    const bool af = c->af_mode != UTM_AF_NONE;  // (k_pick clears the list counters after reading them)
+    unsigned split = (2048 + a_ub - 1) / a_ub;
+    split = std::min(16u, std::max(1u, split));
+    const u64 s_t = interleaved_stride(c);
+    // interleaved form: list slices sized from the last known gain (gains shrink over a run; any value is correct)
+    const unsigned slices = (unsigned)std::min<i64>(256, std::max<i64>(1, c->last_new / 16));
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        Chunk &ch = c->chunks[k];
+        hipLaunchKernelGGL(k_newly, dim3((unsigned)std::min<u64>(1024, (ch.wp / 2 + 511) / 512)), dim3(512), 0, c->stream, ch.covered,
+                           ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, ch.list_idx, ch.list_val, c->d_listn + k);
+        const unsigned *afbits = af ? reinterpret_cast<const unsigned *>(ch.af32) : nullptr;
+        const int e_base = af ? 150 - c->af_q : 0;
+        u64 *cnt = af ? c->d_cnt : c->d_cnt_keep;
+        i64 *afsum = af ? c->d_afsum : c->d_afsum_keep;
+        if (c->decr_interleaved) {
+            const dim3 grid((unsigned)((s_t + 255) / 256), slices);
+            if (af)
+                hipLaunchKernelGGL(k_decr_t<true>, grid, dim3(256), 0, c->stream, ch.rows_t, s_t, afbits, e_base, c->d_st, c->d_state,
+                                   c->n_local, ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
+            else
+                hipLaunchKernelGGL(k_decr_t<false>, grid, dim3(256), 0, c->stream, ch.rows_t, s_t, afbits, e_base, c->d_st, c->d_state,
+                                   c->n_local, ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
+            continue;
+        }
+        const dim3 grid((a_ub + 3) / 4, split);
+        if (af)
+            hipLaunchKernelGGL(k_decr<true>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, afbits, e_base, c->d_st, c->d_act,
+                               ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
+        else
+            hipLaunchKernelGGL(k_decr<false>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, afbits, e_base, c->d_st, c->d_act,
+                               ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
+    }
+    HIP_TRY(hipGetLastError());
+    return UTM_OK;
+}
+
+// Algorithmic HBM bytes of one iteration with `a` selectable local samples:
+// active columns + covered read + winner column re-read + covered write (+ AF values).
+static i64 iteration_bytes(const utm_ctx *c, u64 a)
+{
+    i64 b = 0;
+    for (auto &ch : c->chunks) {
+        b += (i64)((a + 3) * ch.w * 8);
+        if (c->af_mode == UTM_AF_F32) b += (i64)ch.n_var * 4;
+        if (c->af_mode == UTM_AF_F64) b += (i64)ch.n_var * 8;
+    }
+    return b;
+}
+
+// Verified-parallel AF: candidates -> their sequential chains (-> everyone, if too many tie).
+static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
+{
+    if (!a.cand) return;
+    hipLaunchKernelGGL(k_cand, dim3(1), dim3(256), 0, c->stream, a);
+    const unsigned blocks = (std::max(1u, c->active_ub) + 63) / 64;
+    const ChainFast &cf = c->chain_fast;
+    if (c->af_mode == UTM_AF_F32) {
+        if (cf.counts)
+            hipLaunchKernelGGL(k_chain_fill<float>, dim3(cf.n_segs, UTM_FAST_CAND), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
+        hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand, cf);
+        hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                           c->d_act, c->d_cnt, c->d_fscore, 1);
+    } else {
+        if (cf.counts)
+            hipLaunchKernelGGL(k_chain_fill<double>, dim3(cf.n_segs, UTM_FAST_CAND), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
+        hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand, cf);
+        hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                           c->d_act, c->d_cnt, c->d_fscore, 1);
+    }
+}
+
+static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
+{
+    PickArgs a = pick_args(c, decr);
+    enqueue_candidates(c, a);
+    if (c->n_ranks > 1 && c->mbox_ok) {
+        // device-side exchange: post this shard's record into every shard's mailbox, wait for theirs, decide
+        hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, c->stream, a);  // pick, post, collect, decide
+    } else if (c->comm) {
+        hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, c->stream, a);
+        u64 *slot = c->d_xbuf + (u64)c->rank * c->xbuf_slot_words;
+        if (!c->p2p)
+            for (auto &ch : c->chunks)
+                hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                                   slot + UTM_HDR_WORDS + ch.off, ch.cols, ch.wp, c->d_st, c->d_act);
+        HIP_TRY(hipGetLastError());
+        // one collective per iteration: every shard's record (and, without P2P mappings, its candidate column), in place
+        NCCL_TRY(g_rccl.AllGather(slot, c->d_xbuf, c->xbuf_slot_words, ncclUint64, c->comm, c->stream));
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, a);
+    } else if (c->n_ranks == 1) {
+        hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(1024), 0, c->stream, a);
+    } else {
+        return fail(UTM_ESTATE, "sharded context without a fused exchange: use utm_local_best / utm_apply_records, or enable the mailboxes / RCCL");
+    }
+    HIP_TRY(hipGetLastError());
+    return UTM_OK;
+}
+
+// Bring the host mirror up to date with the device after a sync.
+static int sync_state(utm_ctx *c)
+{
+    HIP_TRY(hipMemcpyAsync(c->h_st, c->d_st, sizeof(IterState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->iter = c->h_st->iter;
+    c->captured_seen = c->h_st->tot;
+    c->xseq_host = c->h_st->xseq;
+    if (c->h_st->xerror) return fail(UTM_ECOMM, "a shard's record did not arrive through the mailboxes in time");
+    if (c->h_st->all_exact) c->af_all_exact = true;
+    c->active_ub = c->h_st->n_active;
+    c->finished = c->h_st->done != 0;
+    return UTM_OK;
+}
+
+static int collect_event_times(utm_ctx *c)
+{
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        c->score_ms += ms;
+    }
+    c->ev_used = 0;
+    return UTM_OK;
+}
+
+extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new_out, double *score_out,
+                       int64_t *n_done)
+{
+    CTX(c);
+    if (k_max < 0 || !n_done || (k_max > 0 && (!idx_out || !new_out))) return fail(UTM_EINVAL, "bad outputs");
+    TRY(ensure_prepared(c));
+    *n_done = 0;
+    const i64 iter0 = c->iter;
+    const i64 room = (i64)c->n_total - iter0;
+    if (k_max > room) k_max = room;
+    HIP_TRY(hipEventRecord(c->ev_loop0, c->stream));
+    // iterations enqueued between two host syncs: AF modes latch host-side decisions there (64); the integer loop
+    // only needs the stop flag (256: a boundary costs an idle device for two round trips)
+    static const int batch_env = tune_env("UTM_BATCH", 0);
+    const int batch = batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
+    i64 enq = 0;
+    while (enq < k_max && !c->finished) {
+        // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
+        // ... and so is the switch to decremental iterations
+        const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, 8)
+                               : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, 16)
+                                                                                            : batch;
+        const i64 n = std::min<i64>(this_batch, k_max - enq);
+        const unsigned a0 = c->active_ub;
+        // Decremental batches: only when allowed, when the persistent counts are current, and when the last
+        // winner newly covered few enough variants (gains shrink over a greedy run, so it stays that way).
+        const bool decr = c->decr_enabled && c->keep_valid && c->last_new >= 0 && (c->af_mode == UTM_AF_NONE || c->af_fixed) &&
+                          (double)c->last_new <= (c->decr_threshold > 0 ? c->decr_threshold : c->decr_interleaved ? 0.5 : 0.2) *
+                                                     (double)c->col_words;
+        for (i64 j = 0; j < n; ++j) {
+            if (decr) TRY(enqueue_score_decr(c));
+            else TRY(enqueue_score(c));
+            TRY(enqueue_pick_and_exchange(c, decr));
+            if (c->n_ranks == 1 && c->active_ub > 0) c->active_ub -= 1;  // exact while the loop is alive
+        }
+        enq += n;
+        const i64 before = c->iter;
+        TRY(sync_state(c));
+        // bytes: iterations that were actually scored in this batch (rows + a terminating empty pass); the
+        // local selectable count falls from a0 to a1 over the batch's rows (by one per row on a single shard)
+        const i64 rows = c->iter - before;
+        const i64 passes = std::min<i64>(n, rows + ((c->finished && c->h_st->tot < (i64)c->n_var_total && rows < n) ? 1 : 0));
+        const unsigned a1 = c->active_ub;
+        for (i64 j = 0; j < passes; ++j) {
+            const u64 drop = rows > 0 ? (u64)(a0 - a1) * (u64)std::min(j, rows) / (u64)rows : 0;
+            const i64 full = iteration_bytes(c, a0 - drop);
+            c->brute_bytes += full;
+            if (!decr) c->algo_bytes += full;
+        }
+        if (decr) {
+            // what the decremental iterations had to touch: winner column + covered (read), the list (written
+            // once, read once), covered words rewritten, and one word per (selectable sample, listed word)
+            const u64 entries = c->h_st->decr_entries - c->decr_entries_seen;
+            const u64 gathers = c->h_st->decr_gathers - c->decr_gathers_seen;
+            // (interleaved copy: one word per (sample slot, listed word), selectable or not)
+            const u64 touched = c->decr_interleaved ? entries * interleaved_stride(c) : gathers;
+            c->algo_bytes += (i64)(passes * 2 * (i64)c->col_words * 8 + entries * 32 + touched * 8);
+            c->decr_iterations += passes;
+        }
+        c->decr_entries_seen = c->h_st->decr_entries;
+        c->decr_gathers_seen = c->h_st->decr_gathers;
+        // a full pass mirrored the counts (integer mode with the decremental option) / the AF accumulators are persistent
+        c->keep_valid = c->decr_enabled || (c->af_mode != UTM_AF_NONE && c->af_fixed);
+        if (rows > 0) HIP_TRY(copy_sync(c, &c->last_new, c->d_res_new + c->iter - 1, 8, hipMemcpyDeviceToHost));
+        c->scored += passes;
+        if (c->flags & UTM_FLAG_PROFILE_EVENTS) TRY(collect_event_times(c));
+    }
+    HIP_TRY(hipEventRecord(c->ev_loop1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_loop1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_loop0, c->ev_loop1));
+    c->loop_ms = ms;
+    const i64 rows = c->iter - iter0;
+    if (rows > 0) {
+        HIP_TRY(copy_sync(c, idx_out, c->d_res_idx + iter0, rows * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(c, new_out, c->d_res_new + iter0, rows * 8, hipMemcpyDeviceToHost));
+        if (score_out) HIP_TRY(copy_sync(c, score_out, c->d_res_score + iter0, rows * 8, hipMemcpyDeviceToHost));
+    }
+    *n_done = rows;
+    return UTM_OK;
+}
+
+extern "C" int utm_step(utm_ctx *c, int64_t *idx, int64_t *new_count, double *score)
+{
+    int64_t i = -1, n = 0, done = 0;
+    double s = 0;
+    CTX(c);
+    TRY(ensure_prepared(c));
+    if (!c->finished && c->iter < (i64)c->n_total) TRY(utm_run(c, 1, &i, &n, &s, &done));
+    if (done == 0) { i = -1; n = 0; s = 0; }
+    if (idx) *idx = i;
+    if (new_count) *new_count = n;
+    if (score) *score = s;
+    return UTM_OK;
+}
+
+extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
+{
+    CTX(c);
+    TRY(ensure_prepared(c));
+    // with AF every sample's exact reference score is wanted, so all of them take the sequential chain
+    c->keep_valid = false;  // the pending winner gets applied here: the next iteration must re-score in full
+    TRY(enqueue_score(c, /*force_sequential=*/true));
+    i64 *d_counts = nullptr;
+    double *d_scores = nullptr;
+    HIP_TRY(hipMalloc(&d_counts, (size_t)c->n_local * 8));
+    HIP_TRY(hipMalloc(&d_scores, (size_t)c->n_local * 8));
+    PickArgs pa = pick_args(c);
+    pa.afsum = nullptr;
+    hipLaunchKernelGGL(k_final_scores, dim3((c->n_local + 255) / 256), dim3(256), 0, c->stream, pa, d_counts, d_scores);
+    (void)hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream);
+    (void)hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && counts) e = copy_sync(c, counts, d_counts, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && scores) e = copy_sync(c, scores, d_scores, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_counts);
+    (void)hipFree(d_scores);
+    if (e != hipSuccess) return fail(UTM_EHIP, "peek: %s", hipGetErrorString(e));
+    return UTM_OK;
+}
+
+static int flush_pending(utm_ctx *c)
+{
+    for (auto &ch : c->chunks)
+        hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
+                           ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
+    HIP_TRY(hipGetLastError());
+    return UTM_OK;
+}
+
+extern "C" int utm_get_covered(utm_ctx *c, int32_t chunk, uint64_t *out)
+{
+    CTX(c);
+    Chunk *ch;
+    TRY(chunk_of(c, chunk, &ch));
+    if (!out) return fail(UTM_EINVAL, "out is NULL");
+    TRY(ensure_prepared(c));
+    c->keep_valid = false;
+    TRY(flush_pending(c));
+    HIP_TRY(hipMemcpyAsync(out, ch->covered, ch->w * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return UTM_OK;
+}
+
+extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
+{
+    CTX(c);
+    if (!out) return fail(UTM_EINVAL, "out is NULL");
+    memset(out, 0, sizeof *out);
+    out->iterations = c->iter;
+    out->tot_captured = c->prepared ? c->h_st->tot : 0;
+    out->score_launches = c->score_launches;
+    out->score_ms = c->score_ms;
+    out->loop_ms = c->loop_ms;
+    out->algo_bytes = c->algo_bytes;
+    out->af_mode = c->af_mode;
+    out->af_fixed_point = c->af_fixed;
+    out->af_q = c->af_q;
+    out->n_chunks = (int32_t)c->chunks.size();
+    out->decr_iterations = c->decr_iterations;
+    out->brute_force_bytes = c->brute_bytes;
+    out->p2p_replica_bytes = (i64)c->replica_bytes;
+    out->decr_interleaved_bytes = c->decr_interleaved ? (i64)(c->col_words * interleaved_stride(c) * 8) : 0;
+    return UTM_OK;
+}
+
+extern "C" int utm_set_decremental(utm_ctx *c, int32_t on, double threshold)
+{
+    CTX(c);
+    c->decr_enabled = on != 0;
+    c->decr_threshold = threshold > 0 ? threshold : 0;
+    c->prepared = false;  // buffers are allocated at the next reset
+    return UTM_OK;
+}
+
+extern "C" int utm_set_af_exact_scores(utm_ctx *c, int32_t on)
+{
+    CTX(c);
+    c->af_exact_scores = on != 0;
+    return UTM_OK;
+}
+
+extern "C" int utm_set_profile(utm_ctx *c, int32_t on)
+{
+    CTX(c);
+    if (on) c->flags |= UTM_FLAG_PROFILE_EVENTS;
+    else c->flags &= ~UTM_FLAG_PROFILE_EVENTS;
+    return UTM_OK;
+}

@@ -1,0 +1,174 @@
+// Per-run options: sample states, weights, AF tables (and their exactness analysis), decremental / profile switches.
+// Part of the one translation unit utmos_hip.hip (included there, in order); not a stand-alone header.
+#pragma once
+
+// ---------------------------------------------------------------------------------------- options
+extern "C" int utm_set_sample_state(utm_ctx *c, const uint8_t *state)
+{
+    CTX(c);
+    if (!state) return fail(UTM_EINVAL, "state is NULL");
+    for (uint32_t s = 0; s < c->n_total; ++s)
+        if (state[s] > 2) return fail(UTM_EINVAL, "state[%u] = %u not in {0,1,2}", s, state[s]);
+    c->h_state.assign(state, state + c->n_total);
+    c->prepared = false;
+    return UTM_OK;
+}
+
+extern "C" int utm_set_weights(utm_ctx *c, const double *w)
+{
+    CTX(c);
+    if (!w) {
+        c->have_weights = false;
+        return UTM_OK;
+    }
+    for (uint32_t s = 0; s < c->n_total; ++s)
+        if (!isfinite(w[s])) return fail(UTM_EINVAL, "weights[%u] is not finite", s);
+    if (!c->d_weights) HIP_TRY(hipMalloc(&c->d_weights, (size_t)c->n_total * 8));
+    HIP_TRY(copy_sync(c, c->d_weights, w, (size_t)c->n_total * 8, hipMemcpyHostToDevice));
+    c->have_weights = true;
+    return UTM_OK;
+}
+
+extern "C" int utm_set_af(utm_ctx *c, int32_t chunk, int mode, const void *af)
+{
+    CTX(c);
+    if (mode == UTM_AF_NONE) {
+        if (af) return fail(UTM_EINVAL, "UTM_AF_NONE takes af == NULL");
+        for (auto &ch : c->chunks) { ch.h_af32.clear(); ch.h_af64.clear(); }
+        c->af_mode = UTM_AF_NONE;
+        c->dirty_tables = true;
+        c->prepared = false;
+        return UTM_OK;
+    }
+    Chunk *ch;
+    TRY(chunk_of(c, chunk, &ch));
+    if (mode != UTM_AF_F32 && mode != UTM_AF_F64) return fail(UTM_EINVAL, "mode %d", mode);
+    if (!af) return fail(UTM_EINVAL, "af is NULL");
+    if (c->af_mode != UTM_AF_NONE && c->af_mode != mode) {
+        for (auto &o : c->chunks)
+            if (&o != ch && (!o.h_af32.empty() || !o.h_af64.empty()))
+                return fail(UTM_ESTATE, "all chunks must use one AF mode");
+    }
+    // A variant whose AF is 0.0 is an all-zero row of the reference's float matrix (presence * AF):
+    // never counted, never scored, never covered.  var_count is taken from the boolean matrix
+    // (select.py:281-284), so it is latched before such rows are cleared.
+    std::vector<u64> keep(ch->w, ~0ull);
+    bool any_zero = false;
+    for (u64 v = 0; v < ch->n_var; ++v) {
+        const double a = mode == UTM_AF_F32 ? (double)((const float *)af)[v] : ((const double *)af)[v];
+        if (!isfinite(a) || a < 0) return fail(UTM_EINVAL, "AF[%llu] = %g must be finite and >= 0", v, a);
+        if (a == 0.0) { keep[v >> 6] &= ~(1ull << (v & 63)); any_zero = true; }
+    }
+    if (any_zero) {
+        if (c->exported) return fail(UTM_ESTATE, "the columns are exported to other shards (utm_p2p_export): set the AF before exporting");
+        TRY(ensure_var_count(c));
+        ch->rows_t_valid = false;
+        u64 *d_keep = nullptr;
+        HIP_TRY(hipMalloc(&d_keep, ch->w * 8));
+        HIP_TRY(copy_sync(c, d_keep, keep.data(), ch->w * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_mask_rows, dim3(4096), dim3(256), 0, c->stream, ch->cols, ch->wp, d_keep, ch->w, c->n_local);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_keep);
+        if (e != hipSuccess) return fail(UTM_EHIP, "mask rows: %s", hipGetErrorString(e));
+    }
+    ch->h_af32.clear();
+    ch->h_af64.clear();
+    if (mode == UTM_AF_F32) ch->h_af32.assign((const float *)af, (const float *)af + ch->n_var);
+    else ch->h_af64.assign((const double *)af, (const double *)af + ch->n_var);
+    c->af_mode = mode;
+    c->dirty_tables = true;
+    c->prepared = false;
+    return UTM_OK;
+}
+
+// Decide the AF arithmetic and build the device tables.
+static int build_af_tables(utm_ctx *c)
+{
+    if (!c->dirty_tables) return UTM_OK;
+    for (auto &ch : c->chunks) {
+        if ((void *)ch.af32 != ch.af) (void)hipFree(ch.af32);
+        (void)hipFree(ch.af);
+        ch.af = nullptr;
+        ch.af32 = nullptr;
+    }
+    (void)hipFree(c->d_seq);
+    c->d_seq = nullptr;
+    c->af_fixed = false;
+    c->af_q = 0;
+    if (c->af_mode == UTM_AF_NONE) { c->dirty_tables = false; return UTM_OK; }
+    for (auto &ch : c->chunks)
+        if ((c->af_mode == UTM_AF_F32 ? ch.h_af32.size() : ch.h_af64.size()) != ch.n_var)
+            return fail(UTM_ESTATE, "AF not set for every chunk");
+    // float32 view of the AF values: the data itself (F32) or its rounding (F64, estimate only)
+    std::vector<std::vector<float>> v32(c->chunks.size());
+    bool representable = true;
+    int e_min = 1000, e_max = -1000;
+    long double mass = 0;
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        Chunk &ch = c->chunks[k];
+        v32[k].assign(ch.wp * 64, 0.0f);
+        for (u64 v = 0; v < ch.n_var; ++v) {
+            const float a = c->af_mode == UTM_AF_F32 ? ch.h_af32[v] : (float)ch.h_af64[v];
+            v32[k][v] = a;
+            if (c->af_mode == UTM_AF_F64 && ch.h_af64[v] != 0.0 && (!(a > 0.0f) || !isfinite(a))) representable = false;
+            if (a == 0.0f) continue;
+            if (fpclassify(a) == FP_SUBNORMAL) { representable = false; continue; }
+            int e;
+            frexpf(a, &e);  // a = f * 2^e, f in [0.5, 1): the leading bit has weight 2^(e-1)
+            e_min = std::min(e_min, e - 1);
+            e_max = std::max(e_max, e - 1);
+            mass += a;
+        }
+    }
+    if (e_min == 1000) e_min = e_max = 0;
+    // Every float32 a > 0 is m * 2^(e-23), m < 2^24: a multiple of 2^-q for q = 23 - e_min.  The
+    // estimate kernel sums a * 2^q = m << (e - e_min) as int64: needs q >= 0 and mass * 2^q < 2^62.
+    const int q = 23 - e_min;
+    if (!(c->flags & UTM_FLAG_AF_SEQUENTIAL) && representable && q >= 0 && q <= 149 &&
+        e_max - e_min <= 38 && mass * ldexpl(1.0L, q - 62) < 1.0L) {
+        c->af_fixed = true;
+        c->af_q = q;
+    }
+    std::vector<SeqChunk> seq;
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        Chunk &ch = c->chunks[k];
+        const size_t n = ch.wp * 64;
+        HIP_TRY(hipMalloc(&ch.af32, n * 4));
+        HIP_TRY(copy_sync(c, ch.af32, v32[k].data(), n * 4, hipMemcpyHostToDevice));
+        if (c->af_mode == UTM_AF_F32) {
+            ch.af = ch.af32;
+        } else {
+            HIP_TRY(hipMalloc(&ch.af, n * 8));
+            // (the context's stream is non-blocking: never mix in null-stream work, it would not be ordered with it)
+            HIP_TRY(hipMemsetAsync(ch.af, 0, n * 8, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(copy_sync(c, ch.af, ch.h_af64.data(), ch.n_var * 8, hipMemcpyHostToDevice));
+        }
+        seq.push_back(SeqChunk{ch.cols, ch.covered, ch.af, ch.wp, ch.w});
+    }
+    HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
+    HIP_TRY(copy_sync(c, c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
+    // segment table + buffers of the chains' fast path
+    (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
+    c->d_segs = nullptr;
+    c->chain_fast = ChainFast{nullptr, 0, nullptr, nullptr};
+    if (c->af_fixed)
+        for (auto &ch : c->chunks)
+            if (!ch.mask) HIP_TRY(hipMalloc(&ch.mask, ch.wp * 8));
+    if (c->af_fixed) {
+        std::vector<ChainSeg> segs;
+        for (size_t k = 0; k < c->chunks.size(); ++k)
+            for (u64 w0 = 0; w0 < c->chunks[k].w; w0 += UTM_SEG_WORDS) segs.push_back(ChainSeg{(int)k, w0});
+        const size_t n = segs.size();
+        if (n * UTM_FAST_CAND * UTM_SEG_CAP * 8 <= (4ull << 30)) {  // keep the scratch within 4 GiB
+            HIP_TRY(hipMalloc(&c->d_segs, n * sizeof(ChainSeg)));
+            HIP_TRY(copy_sync(c, c->d_segs, segs.data(), n * sizeof(ChainSeg), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc(&c->chain_fast.counts, n * UTM_FAST_CAND * 4));
+            HIP_TRY(hipMalloc(&c->chain_fast.vals, n * UTM_FAST_CAND * UTM_SEG_CAP * 8));
+            c->chain_fast.segs = c->d_segs;
+            c->chain_fast.n_segs = (int)n;
+        }
+    }
+    c->dirty_tables = false;
+    return UTM_OK;
+}
