@@ -146,7 +146,7 @@ int utm_get_stats(utm_ctx *ctx, utm_stats *out);
  * covered word is then one contiguous read over all samples instead of one 8-byte gather per column
  * (utm_stats.decr_interleaved_bytes; UTM_DECR_INTERLEAVED=0 or lack of room keeps the gather form).
  * threshold = largest fraction of a column's words that may be newly covered for an iteration to go
- * decremental (<= 0: default -- 0.5 with the interleaved copy, 0.2 gathering). */
+ * decremental (<= 0: default -- 1.0 with the interleaved copy, 0.2 gathering). */
 int utm_set_decremental(utm_ctx *ctx, int32_t on, double threshold);
 /* AF modes: the winner of an iteration is always the reference's (sample order, new_count are exact).  The reported
  * *score* is, by default (on = 1), also the reference's float64 running sum bit for bit, which costs one sequential

@@ -312,20 +312,21 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     // iterations enqueued between two host syncs: AF modes latch host-side decisions there (64); the integer loop
     // only needs the stop flag (256: a boundary costs an idle device for two round trips)
     static const int batch_env = tune_env("UTM_BATCH", 0);
+    static const int decr_first = std::max(1, tune_env("UTM_DECR_FIRST_BATCH", 8));
     const int batch = batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
     i64 enq = 0;
     while (enq < k_max && !c->finished) {
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
         // ... and so is the switch to decremental iterations
         const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, 8)
-                               : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, 16)
+                               : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, decr_first)
                                                                                             : batch;
         const i64 n = std::min<i64>(this_batch, k_max - enq);
         const unsigned a0 = c->active_ub;
         // Decremental batches: only when allowed, when the persistent counts are current, and when the last
         // winner newly covered few enough variants (gains shrink over a greedy run, so it stays that way).
         const bool decr = c->decr_enabled && c->keep_valid && c->last_new >= 0 && (c->af_mode == UTM_AF_NONE || c->af_fixed) &&
-                          (double)c->last_new <= (c->decr_threshold > 0 ? c->decr_threshold : c->decr_interleaved ? 0.5 : 0.2) *
+                          (double)c->last_new <= (c->decr_threshold > 0 ? c->decr_threshold : c->decr_interleaved ? 1.0 : 0.2) *
                                                      (double)c->col_words;
         for (i64 j = 0; j < n; ++j) {
             if (decr) TRY(enqueue_score_decr(c));

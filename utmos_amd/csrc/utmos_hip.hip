@@ -160,7 +160,7 @@ struct utm_ctx {
     size_t listn_cap = 0;
     bool decr_enabled = false;
     bool decr_interleaved = false;  // the chunks carry a word-interleaved copy: decremental iterations stream it
-    double decr_threshold = 0;  // <= 0: by layout (0.5 streaming the interleaved copy, 0.2 gathering)
+    double decr_threshold = 0;  // <= 0: by layout (1.0 streaming the interleaved copy, 0.2 gathering)
     bool keep_valid = false;     // the persistent counts describe the state right before the pending winner
     i64 last_new = -1;           // new_count of the last row (host copy)
     i64 decr_iterations = 0;
