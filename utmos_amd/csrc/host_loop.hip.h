@@ -470,6 +470,15 @@ extern "C" int utm_set_decremental(utm_ctx *c, int32_t on, double threshold)
     CTX(c);
     c->decr_enabled = on != 0;
     c->decr_threshold = threshold > 0 ? threshold : 0;
+    if (!on) {  // the interleaved copy doubles the matrix: hand it back with the mode
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (auto &ch : c->chunks) {
+            (void)hipFree(ch.rows_t);
+            ch.rows_t = nullptr;
+            ch.rows_t_valid = false;
+        }
+        c->decr_interleaved = false;
+    }
     c->prepared = false;  // buffers are allocated at the next reset
     return UTM_OK;
 }
