@@ -116,7 +116,9 @@ def main():
     n_total = args.n_samp
     first = rank * n_total // world
     n_local = (rank + 1) * n_total // world - first
-    m = device.DeviceMatrix(n_total, device=local_rank, first_sample=first, n_local=n_local)
+    n_dev = device.nat.device_count()
+    dev_index = local_rank % n_dev        # one GPU per rank on a full node; ranks share devices only on smaller test boxes
+    m = device.DeviceMatrix(n_total, device=dev_index, first_sample=first, n_local=n_local)
     chunk_vars = args.chunk_vars or args.n_var
     v0 = 0
     t_gen = time.perf_counter()
@@ -235,7 +237,7 @@ def main():
     # from this very run that the sharded exchange decides exactly like a single GPU
     sharded_check = None
     if (world > 1 or args.force_comm) and rank == 0 and not args.no_sharded_check:
-        with device.DeviceMatrix(n_total, device=local_rank) as solo:
+        with device.DeviceMatrix(n_total, device=dev_index) as solo:
             v0 = 0
             while v0 < args.n_var:
                 nv = min(chunk_vars, args.n_var - v0)

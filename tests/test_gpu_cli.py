@@ -206,3 +206,26 @@ def test_cli_select_all_until_every_variant_is_captured(extra, tmp_path):
     got = open(out).read()
     assert got == expected
     assert got.count("\n") > 1000 and got.rstrip().endswith("\t1.0")
+
+
+def test_bench_and_cli_under_torchrun_two_ranks(tmp_path):
+    """The driver's launch line for N > 1 -- python -m torch.distributed.run --nproc-per-node N ... -- with both
+    ranks on the box's one GPU (LOCAL_RANK wraps around the visible devices): bench.py prints its line and matches
+    its own single-GPU re-run; `-m utmos_amd select` writes the golden TSV.  torch lives in the launcher only."""
+    import json
+    import subprocess
+    import sys
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    env = dict(os.environ, TMPDIR=str(tmp_path))
+    port = 43500 + os.getpid() % 2000
+    out = subprocess.run(launch + ["--master-port", str(port), os.path.join(ou.ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                                   "--warmup", "1", "--n-var", "300000", "--n-samp", "200", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ou.ROOT)
+    assert out.returncode == 0, out.stderr[-800:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["sharded_rows_match_single_gpu"] is True and line["config"]["iterations_per_step"] == 200
+    argv, tsv = cli_args(CASES["select_multi"], tmp_path)
+    out = subprocess.run(launch + ["--master-port", str(port + 1), "-m", "utmos_amd", "select"] + argv,
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ou.ROOT)
+    assert out.returncode == 0, out.stderr[-800:]
+    assert open(tsv).read() == ou.golden_text(CASES["select_multi"])

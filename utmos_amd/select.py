@@ -375,7 +375,8 @@ def select_main(cmdargs):
     from .sharded import bootstrap, dist_env, enable_p2p
     rank, world, local_rank = dist_env()
     shard = (rank, world) if world > 1 else None
-    dev = local_rank if world > 1 and "--device" not in cmdargs else args.device
+    # one GPU per rank on a full node (ranks share devices only on smaller test boxes)
+    dev = local_rank % device.nat.device_count() if world > 1 and "--device" not in cmdargs else args.device
     data = load_files(args.in_files, args.lowmem, args.buffer, args.af, dev, shard)
     if not args.brute_force:
         data["data"].set_decremental(True)      # exact; same rows (DESIGN.md "Decremental scoring")
