@@ -210,27 +210,36 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
         const char *env = getenv("UTM_P2P_REPLICATE");
         const bool wanted = n_ranks > 1 && !(env && *env == '0');
         if (wanted && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (u64)free_b > need + (8ull << 30)) {
-            bool ok = true;
-            for (size_t k = 0; k < c->chunks.size() && ok; ++k) {
-                Chunk &ch = c->chunks[k];
-                ok = hipMalloc(&ch.replica, (size_t)(need / c->col_words * ch.wp)) == hipSuccess;
-                u64 off = 0;
-                for (int r = 0; r < n_ranks && ok; ++r) {
-                    if (r == rank) continue;
-                    const u64 words = (u64)locals[r] * ch.wp;
-                    hipLaunchKernelGGL(k_copy_remote, dim3(2048), dim3(256), 0, c->stream, table[k][r], ch.replica + off, words);
-                    table[k][r] = ch.replica + off;
-                    off += words;
-                }
-            }
-            if (ok) ok = hipStreamSynchronize(c->stream) == hipSuccess;
-            if (!ok) {
+            // allocate everything first: a refusal (another process took the room meanwhile) just keeps the in-place reads
+            bool room = true;
+            for (auto &ch : c->chunks)
+                if (room && hipMalloc(&ch.replica, (size_t)(need / c->col_words * ch.wp)) != hipSuccess) room = false;
+            if (!room) {
                 (void)hipGetLastError();
-                p2p_close(c);
-                return fail(UTM_EHIP, "copying the peers' columns failed");
+                for (auto &ch : c->chunks) {
+                    (void)hipFree(ch.replica);
+                    ch.replica = nullptr;
+                }
+            } else {
+                for (size_t k = 0; k < c->chunks.size(); ++k) {
+                    Chunk &ch = c->chunks[k];
+                    u64 off = 0;
+                    for (int r = 0; r < n_ranks; ++r) {
+                        if (r == rank) continue;
+                        const u64 words = (u64)locals[r] * ch.wp;
+                        hipLaunchKernelGGL(k_copy_remote, dim3(2048), dim3(256), 0, c->stream, table[k][r], ch.replica + off, words);
+                        table[k][r] = ch.replica + off;
+                        off += words;
+                    }
+                }
+                if (hipStreamSynchronize(c->stream) != hipSuccess) {  // a fault reading a peer: no P2P at all on this shard
+                    (void)hipGetLastError();
+                    p2p_close(c);
+                    return fail(UTM_EHIP, "copying the peers' columns failed");
+                }
+                c->replicated = true;
+                c->replica_bytes = need;
             }
-            c->replicated = true;
-            c->replica_bytes = need;
         }
     }
     HIP_TRY(hipMalloc(&c->d_peer_first, (size_t)n_ranks * 4));
