@@ -247,6 +247,10 @@ static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
 
 static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
 {
+    static const int pick_env = tune_env("UTM_PICK_THREADS", 0);
+    // single shard: 512 threads scan a few thousand counts as fast as 1024 and launch / join quicker (1024, 512, 256,
+    // 128, 64 threads: 626.8, 623.6, 625.1, 629.6, 641.3 ms per cfg2 run)
+    const unsigned pick_threads = pick_env ? (unsigned)pick_env : c->active_ub > 16384 ? 1024 : 512;
     PickArgs a = pick_args(c, decr);
     enqueue_candidates(c, a);
     if (c->n_ranks > 1 && c->mbox_ok) {
@@ -264,7 +268,7 @@ static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
         NCCL_TRY(g_rccl.AllGather(slot, c->d_xbuf, c->xbuf_slot_words, ncclUint64, c->comm, c->stream));
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, a);
     } else if (c->n_ranks == 1) {
-        hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(1024), 0, c->stream, a);
+        hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(pick_threads), 0, c->stream, a);
     } else {
         return fail(UTM_ESTATE, "sharded context without a fused exchange: use utm_local_best / utm_apply_records, or enable the mailboxes / RCCL");
     }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
     Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
     if (src == 3) {
         const unsigned n_cand = (unsigned)st->n_cand;
-        for (unsigned b = threadIdx.x; b < n_cand; b += 1024) {
+        for (unsigned b = threadIdx.x; b < n_cand; b += blockDim.x) {
             const unsigned s = a.cand->samp[b];
             double v = a.cand->val[b];
             if (a.weights) v *= a.weights[a.first + s];
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
             if (better(cand, best)) best = cand;
         }
     }
-    for (unsigned i = threadIdx.x; i < n_active; i += 1024) {
+    for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
         const unsigned s = a.act[i];
         const u64 c = a.cnt[s];
         if (a.zero_after) a.cnt[s] = 0;  // ready for the next iteration's atomics
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
     if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w)
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
             if (better(wbest[w], best)) best = wbest[w];
         Rec *rc = rec_of(a, a.rank);
         rc->score = n_active ? best.val : 0.0;
