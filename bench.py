@@ -50,8 +50,57 @@ def parse():
     p.add_argument("--exchange", choices=["auto", "rccl"], default="auto",
                    help="N > 1: auto = device mailboxes over hipIpc mappings when every rank can, else RCCL; rccl = force RCCL")
     p.add_argument("--decr-threshold", type=float, default=0.0, help="--decremental: newly-covered word fraction below which an iteration goes decremental (0 = library default)")
+    p.add_argument("--pmc-traffic", choices=["live", "recorded", "off"], default="live",
+                   help="roofline.traffic: live = two rocprofv3 --pmc child runs of one step of this workload (N = 1), "
+                        "falling back to the passes recorded under profiles/; recorded = only those; off = null")
     p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the exchange path)")
     return p.parse_args()
+
+
+def live_pmc_traffic(args):
+    """HBM bytes per scoring launch from the PMC counters, as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE and
+    WRITE_SIZE in separate `rocprofv3 --pmc` passes with nothing else enabled (KiB units; on gfx950 FETCH_SIZE reports
+    half of a wide coalesced read -> x2).  Each pass is a child process running ONE step of this same workload.
+    -> (mean bytes per launch, launches, note) or None when the profiler is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    work = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-pass", "--pmc-traffic", "off",
+            "--n-var", str(args.n_var), "--n-samp", str(args.n_samp), "--select", str(args.select), "--seed", str(args.seed),
+            "--chunk-vars", str(args.chunk_vars)]
+    if args.af:
+        work += ["--af", "--af-dtype", args.af_dtype]
+    if args.af_estimate_scores:
+        work += ["--af-estimate-scores"]
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    per_launch = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out_dir = tempfile.mkdtemp(prefix="utm_pmc_", dir=tmp)
+        try:
+            run = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--",
+                                  sys.executable, os.path.abspath(__file__)] + work,
+                                 cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(out_dir, "**", "*_counter_collection.csv"), recursive=True)
+            if run.returncode != 0 or not files:
+                return None
+            with open(max(files, key=os.path.getmtime)) as fh:
+                per_launch[counter] = [float(r["Counter_Value"]) for r in csv.DictReader(fh)
+                                       if "k_score_" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    n = min(len(per_launch["FETCH_SIZE"]), len(per_launch["WRITE_SIZE"]))
+    if n == 0:
+        return None
+    total = sum(per_launch["FETCH_SIZE"][:n]) * 1024 * 2 + sum(per_launch["WRITE_SIZE"][:n]) * 1024
+    return total / n, n, ("live: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child runs of one step of this workload; "
+                          "read bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950), write bytes = WRITE_SIZE KiB x 1024")
 
 
 def rendezvous_id(rank, world, make_id):
@@ -223,15 +272,19 @@ def main():
                         "algo_bytes_per_launch": ps["algo_bytes"] / max(1, ps["score_launches"]),
                         "rank": rank}
 
-    # PMC traffic cannot be read from inside the process: report the recorded rocprofv3 --pmc passes of this
-    # same workload (tools/summarize_profile.py -> profiles/), when it is the default configuration
-    if roofline is not None and args.n_var == 10_000_000 and n_total == 2504 and args.select < 0 and world == 1 \
-            and not args.chunk_vars and (not args.af or args.af_dtype == "f32"):
-        rec = os.path.join(ROOT, "profiles", "r01_cfg3_pmc_hbm.json" if args.af else "r01_cfg2_pmc_hbm.json")
-        if os.path.exists(rec):
-            with open(rec) as fh:
-                roofline["traffic"] = json.load(fh)["hbm_bytes_per_launch_mean"]
-            roofline["traffic_source"] = os.path.relpath(rec, ROOT) + " (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+    # PMC traffic cannot be read from inside the process: two counter passes in child processes (N = 1), else the
+    # passes recorded under profiles/ for the default configurations (tools/summarize_profile.py)
+    if roofline is not None and args.pmc_traffic != "off":
+        live = live_pmc_traffic(args) if args.pmc_traffic == "live" and world == 1 else None
+        if live is not None:
+            roofline["traffic"], roofline["traffic_launches"], roofline["traffic_source"] = live
+        elif args.n_var == 10_000_000 and n_total == 2504 and args.select < 0 and world == 1 \
+                and not args.chunk_vars and (not args.af or args.af_dtype == "f32"):
+            rec = os.path.join(ROOT, "profiles", "r01_cfg3_pmc_hbm.json" if args.af else "r01_cfg2_pmc_hbm.json")
+            if os.path.exists(rec):
+                with open(rec) as fh:
+                    roofline["traffic"] = json.load(fh)["hbm_bytes_per_launch_mean"]
+                roofline["traffic_source"] = os.path.relpath(rec, ROOT) + " (recorded rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
 
     # N > 1: rank 0 re-runs the whole problem alone (untimed, own context) and compares the rows -- evidence
     # from this very run that the sharded exchange decides exactly like a single GPU

@@ -229,3 +229,30 @@ def test_bench_and_cli_under_torchrun_two_ranks(tmp_path):
                          env=env, capture_output=True, text=True, timeout=600, cwd=ou.ROOT)
     assert out.returncode == 0, out.stderr[-800:]
     assert open(tsv).read() == ou.golden_text(CASES["select_multi"])
+
+
+def test_bench_line_contract_single_gpu(tmp_path):
+    """One rank, small workload: the one JSON line carries the contract's keys, a roofline object whose live PMC
+    traffic (two rocprofv3 --pmc child runs) is close to the algorithmic bytes, and a cpu_baseline timed on the oracle."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ou.ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n-var", "2000000",
+                          "--n-samp", "500", "--cpu-sample-vars", "20000"],
+                         env=dict(os.environ, TMPDIR=str(tmp_path)), capture_output=True, text=True, timeout=900, cwd=ou.ROOT)
+    assert out.returncode == 0, out.stderr[-800:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1                                             # exactly one line on stdout
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["vs_baseline"] is None and j["dtype"] == "u64"
+    assert j["unit"] == "iterations/s" and j["value"] > 0 and j["config"]["iterations_per_step"] == 500
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and 0 < r["frac"] < 1
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is not None and r["traffic_source"].startswith("live")
+    assert 0.9 < r["traffic"] / r["algo_bytes_per_launch"] < 1.3      # nothing re-read wholesale, nothing skipped
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "iterations/s"
