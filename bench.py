@@ -70,6 +70,8 @@ def live_pmc_traffic(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None      # this process is itself being profiled: no nested profiler runs
     work = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-pass", "--pmc-traffic", "off",
             "--n-var", str(args.n_var), "--n-samp", str(args.n_samp), "--select", str(args.select), "--seed", str(args.seed),
             "--chunk-vars", str(args.chunk_vars)]
