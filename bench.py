@@ -26,6 +26,19 @@ T_START = time.time()
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+# BASELINE.json `configs`, by name.  cfg2 is the default (the metric's configuration); cfg4 is meant for --gpus 8
+# (12,500 columns = 78 GB per rank) and cfg5 for one GPU (156 GB in ten chunks); both select a fixed number of
+# samples instead of all of them.
+WORKLOADS = {
+    "cfg1": ("1.1M x 2,504 (chr22-sized), select all", dict(n_var=1_103_547, n_samp=2504, select=-1)),
+    "cfg2": ("10M x 2,504, select all", dict(n_var=10_000_000, n_samp=2504, select=-1)),
+    "cfg3": ("10M x 2,504 with float32 AF weighting, select all", dict(n_var=10_000_000, n_samp=2504, select=-1, af=True)),
+    "cfg4": ("50M x 100,000 over the ranks, first 20 iterations", dict(n_var=50_000_000, n_samp=100_000, select=20)),
+    "cfg5": ("500M x 2,504 in chunks of 50M, first 10 iterations",
+             dict(n_var=500_000_000, n_samp=2504, select=10, chunk_vars=50_000_000)),
+}
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -53,8 +66,15 @@ def parse():
     p.add_argument("--pmc-traffic", choices=["live", "recorded", "off"], default="live",
                    help="roofline.traffic: live = two rocprofv3 --pmc child runs of one step of this workload (N = 1), "
                         "falling back to the passes recorded under profiles/; recorded = only those; off = null")
+    p.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
+                   help="a BASELINE.json configuration by name (sets the shape flags): " +
+                        "; ".join(f"{k}: {v[0]}" for k, v in sorted(WORKLOADS.items())))
     p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the exchange path)")
-    return p.parse_args()
+    args = p.parse_args()
+    if args.workload:
+        for key, value in WORKLOADS[args.workload][1].items():
+            setattr(args, key, value)
+    return args
 
 
 def live_pmc_traffic(args):
@@ -277,7 +297,9 @@ def main():
     # PMC traffic cannot be read from inside the process: two counter passes in child processes (N = 1), else the
     # passes recorded under profiles/ for the default configurations (tools/summarize_profile.py)
     if roofline is not None and args.pmc_traffic != "off":
-        live = live_pmc_traffic(args) if args.pmc_traffic == "live" and world == 1 else None
+        # (the child holds a second copy of the matrix next to this process's: only when that is a small part of the HBM)
+        fits_twice = args.n_var * n_total / 8 < 0.25 * device.nat.device_memory(dev_index)[1]
+        live = live_pmc_traffic(args) if args.pmc_traffic == "live" and world == 1 and fits_twice else None
         if live is not None:
             roofline["traffic"], roofline["traffic_launches"], roofline["traffic_source"] = live
         elif args.n_var == 10_000_000 and n_total == 2504 and args.select < 0 and world == 1 \
