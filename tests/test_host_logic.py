@@ -183,3 +183,25 @@ def test_bootstrap_over_the_rendezvous_file_and_an_ephemeral_port(tmp_path):
     assert all(r[2] == [(0.0, 0, 0), (1.0, 1, 10), (2.0, 2, 20)] for r in res)
     assert all(r[3] == [b"\x00" * 5, b"\x01" * 5, b"\x02" * 5] for r in res)
     assert all(r[4] == [0, 1, 2, 3] for r in res)
+
+
+def test_bench_workload_presets_and_profiler_guard(monkeypatch):
+    """bench.py host logic that needs no GPU: --workload expands to BASELINE.json's shapes; no nested profiler
+    runs when the process is itself being profiled."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ou.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "cfg4", "--gpus", "8"])
+    a = bench.parse()
+    assert (a.n_var, a.n_samp, a.select, a.gpus) == (50_000_000, 100_000, 20, 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--workload", "cfg3"])
+    a = bench.parse()
+    assert a.af and a.af_dtype == "f32" and (a.n_var, a.n_samp, a.select) == (10_000_000, 2504, -1)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.n_var, a.n_samp, a.select, a.steps, a.warmup, a.gpus) == (10_000_000, 2504, -1, 5, 2, 1)   # = cfg2
+    assert bench.WORKLOADS["cfg2"][1] == dict(n_var=a.n_var, n_samp=a.n_samp, select=a.select)
+    monkeypatch.setenv("ROCPROFILER_TEST_MARK", "1")
+    assert bench.live_pmc_traffic(a) is None
