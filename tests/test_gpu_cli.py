@@ -49,6 +49,28 @@ def test_cli_forced_chunking_is_result_neutral(name, tmp_path):
     assert open(out).read() == ou.golden_text(CASES[name])
 
 
+def test_input_files_are_merged_into_chunks_up_to_maxmem(monkeypatch):
+    """Three input parts -> one chunk (every chunk costs launches in every iteration); a cap smaller than two parts
+    -> one chunk per part; --maxmem 0 -> `buffer`-sized chunks.  The matrix (var_count, variant total) is the same."""
+    from utmos_amd import select
+    files = [os.path.join(ou.GOLD, n + ".npz") for n in ("chunk0", "chunk1", "chunk2")]
+    shapes = {}
+    for label, maxmem, buffer in (("merged", 2, 32768), ("forced", 0, 256)):
+        monkeypatch.setattr(select, "MAXMEM", maxmem)
+        data = select.load_files(files, None, buffer, True)
+        shapes[label] = (list(data["data"].chunk_vars), data["var_count"].tolist(), data["data"].shape)
+        data["data"].close()
+    assert len(shapes["merged"][0]) == 1 and len(shapes["forced"][0]) > 6
+    assert sum(shapes["merged"][0]) == sum(shapes["forced"][0])
+    assert shapes["merged"][1:] == shapes["forced"][1:]
+    one_part = max(ou.load_part(n)["GT"].shape[0] for n in ("chunk0", "chunk1", "chunk2"))
+    monkeypatch.setattr(select, "is_memsafe", lambda shape, with_af=False: shape[0] <= one_part)     # cap: one part
+    monkeypatch.setattr(select, "MAXMEM", 2)
+    data = select.load_files(files, None, 32768, False)
+    assert len(data["data"].chunk_vars) == 3 and sum(data["data"].chunk_vars) == sum(shapes["merged"][0])
+    data["data"].close()
+
+
 def test_cli_lowmem_store_create_and_reuse(tmp_path):
     # utmos_ssshtests.sh:197-216: create the store, then reuse it via --lowmem and as the only input
     store = str(tmp_path / "tiny.utm")

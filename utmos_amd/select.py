@@ -218,6 +218,20 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0, shard=
     samples = None
     matrix = None
     af_parts = []
+    held_rows, held_af = [], []          # consecutive parts waiting to become one chunk
+
+    def flush():
+        """The held parts become one chunk: every chunk costs its own launches in every iteration, so a run over
+        many input files should not end up with one small chunk per file."""
+        if not held_rows:
+            return
+        rows = held_rows[0] if len(held_rows) == 1 else np.concatenate(held_rows)
+        chunk = matrix.add_chunk(len(rows))
+        matrix.upload_rows_packed(chunk, rows)
+        af_parts.append(held_af[0] if len(held_af) == 1 else np.concatenate(held_af))
+        held_rows.clear()
+        held_af.clear()
+
     for load_count, path in enumerate(in_files):
         dat = _read_part(path)
         if samples is None:
@@ -228,16 +242,25 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0, shard=
         logging.debug("fitering %d uninformative variants", int((~informative).sum()))
         rows = rows[informative]
         af = np.asarray(dat["AF"], dtype=np.float64).reshape(-1)[informative]
-        # one chunk per `step` variants: everything in one chunk unless the estimate says otherwise
         if len(rows) == 0:
             continue                            # a part without a single carrier contributes nothing
-        step = len(rows) if (MAXMEM != 0 and is_memsafe((len(rows), len(samples)), calc_af)) else max(64, buffer // 64 * 64)
-        for lo in range(0, len(rows), max(step, 1)):
-            part = rows[lo:lo + step]
-            chunk = matrix.add_chunk(len(part))
-            matrix.upload_rows_packed(chunk, part)
-            af_parts.append(af[lo:lo + step])
+        if MAXMEM != 0 and is_memsafe((len(rows), len(samples)), calc_af):
+            # parts are merged while the chunk stays within --maxmem (is_memsafe: the policy never changes results)
+            held = sum(len(r) for r in held_rows)
+            if held and not is_memsafe((held + len(rows), len(samples)), calc_af):
+                flush()
+            held_rows.append(rows)
+            held_af.append(af)
+        else:
+            # chunking forced (--maxmem 0) or a part too large for one chunk: `buffer` variants per chunk
+            flush()
+            step = max(64, buffer // 64 * 64)
+            for lo in range(0, len(rows), step):
+                held_rows.append(rows[lo:lo + step])
+                held_af.append(af[lo:lo + step])
+                flush()
         logging.debug("Loaded %d of %d", load_count + 1, len(in_files))
+    flush()
 
     ret = {"samples": samples, "data": matrix}
     # before AF == 0 rows are cleared, like select.py:281-284.  (A shard counts its own samples; select_main
