@@ -69,6 +69,14 @@ def test_input_files_are_merged_into_chunks_up_to_maxmem(monkeypatch):
     data = select.load_files(files, None, 32768, False)
     assert len(data["data"].chunk_vars) == 3 and sum(data["data"].chunk_vars) == sum(shapes["merged"][0])
     data["data"].close()
+    # a part larger than --maxmem is cut into the largest memsafe pieces (not into `buffer`-sized ones)
+    monkeypatch.undo()
+    monkeypatch.setattr(select, "MAXMEM", 1e-4)                      # 100 kB: about 300 of a part's 1,000 variants
+    data = select.load_files(files, None, 64, False)
+    sizes = list(data["data"].chunk_vars)
+    assert sum(sizes) == sum(shapes["merged"][0]) and data["var_count"].tolist() == shapes["merged"][1]
+    assert max(sizes) > 64 and all(select.is_memsafe((n, len(data["samples"]))) for n in sizes)
+    data["data"].close()
 
 
 def test_cli_lowmem_store_create_and_reuse(tmp_path):

@@ -252,9 +252,15 @@ def load_files(in_files, lowmem=None, buffer=32768, calc_af=False, dev=0, shard=
             held_rows.append(rows)
             held_af.append(af)
         else:
-            # chunking forced (--maxmem 0) or a part too large for one chunk: `buffer` variants per chunk
+            # a part too large for one chunk is cut into the largest memsafe pieces; `buffer` variants per chunk only
+            # when chunking is forced (--maxmem 0, the reference's test hook): chunks are HBM allocations here, not
+            # the I/O granularity they are for the reference's hdf5 appends, and each one costs launches per iteration
             flush()
-            step = max(64, buffer // 64 * 64)
+            if MAXMEM != 0:
+                per_variant = len(samples) / 8 + (8 if calc_af else 0)
+                step = max(64, int(MAXMEM * 1e9 / per_variant) // 64 * 64 - 64)
+            else:
+                step = max(64, buffer // 64 * 64)
             for lo in range(0, len(rows), step):
                 held_rows.append(rows[lo:lo + step])
                 held_af.append(af[lo:lo + step])
