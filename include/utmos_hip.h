@@ -70,7 +70,8 @@ typedef struct utm_stats {
     double loop_ms;          /* HIP-event time of the last utm_run (stream time, first launch to last) */
     int64_t algo_bytes;      /* algorithmic HBM bytes of the iterations since the last utm_reset */
     int32_t af_mode;         /* UTM_AF_* in effect */
-    int32_t af_fixed_point;  /* 1 when F32 AF runs as exact int64 fixed point, 0 when sequential */
+    int32_t af_fixed_point;  /* AF estimate: 1 = int64 fixed point at a unit no AF value loses a bit to, 2 = coarser unit
+                              * (mass would overflow: addends floored, intervals widened), 0 = sequential kernel */
     int32_t af_q;            /* fixed-point scale: scores = sum / 2^q */
     int32_t n_chunks;
     int64_t decr_iterations;   /* iterations scored decrementally (0 unless enabled) */

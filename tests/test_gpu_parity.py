@@ -172,13 +172,43 @@ def test_af_dense_and_sparse_kernels_agree(dev, switch, monkeypatch):
     check_run(dev, dense, af=af.astype(np.float64) / 3.0, chunks=[0, 8192 * 3, n_var])
 
 
-def test_af_f32_falls_back_when_not_representable(dev):
+@pytest.mark.parametrize("kind", ["f32", "f64"])
+def test_af_table_too_wide_for_a_lossless_unit_gets_a_coarser_one(dev, kind):
+    """An AF table whose mass times 2^q overflows int64 at the lossless q (a 1e-30 among ordinary values; uniformly
+    random doubles over a million variants behave the same): the estimate floors the smallest values to a coarser
+    unit and the verification widens its intervals by one unit per addend -- still the reference's rows and float64
+    scores bit for bit, and still the parallel kernels."""
     rng = np.random.default_rng(10)
     dense = ou.random_dense(rng, 2000, 50)
-    af = rng.random(2000).astype(np.float32)
-    af[0] = np.float32(1e-30)                       # exponent span too wide for int64 fixed point
-    _, stats = check_run(dev, dense, af=af)
-    assert stats["af_fixed_point"] == 0             # sequential kernel, still bit exact
+    af = rng.random(2000)
+    af[0] = 1e-30
+    af[1:40] *= 1e-9                                  # values far below the unit, carried by many samples
+    dense[:40, :25] = True
+    _, stats = check_run(dev, dense, af=af.astype(np.float32) if kind == "f32" else af)
+    assert stats["af_fixed_point"] == 2
+    w = rng.choice([0.5, 1.0, -1.0, 3.0], 50)
+    check_run(dev, dense, af=af.astype(np.float32) if kind == "f32" else af, weights=w, decremental=1.0)
+
+
+@pytest.mark.parametrize("estimate", [False, True])
+def test_af_coarse_unit_score_floored_to_zero_still_yields_its_row(dev, estimate):
+    """A sample whose only new variant has an AF far below the (coarse) unit: its estimate is 0, its score is not --
+    the loop must not take the estimate for the stop rule's `score == 0` (select.py:51), even when the caller asked
+    for estimated scores."""
+    dense = np.zeros((4, 2), bool)
+    dense[0, 0] = True
+    dense[1, 1] = True
+    af = np.array([1e-30, 1.0, 0.5, 0.25])
+    got, stats = check_run(dev, dense, af=af, estimate_scores=estimate)
+    assert stats["af_fixed_point"] == 2 and got[0].tolist() == [1, 0] and got[2][1] == 1e-30
+
+
+def test_af_sequential_kernel_on_request(dev):
+    rng = np.random.default_rng(11)
+    dense = ou.random_dense(rng, 3000, 40)
+    af = rng.random(3000).astype(np.float32)
+    _, stats = check_run(dev, dense, af=af, af_sequential=True)
+    assert stats["af_fixed_point"] == 0             # one lane per sample, the reference's order: slow, bit exact
 
 
 def test_af_f32_sums_beyond_exact_range_use_chains(dev):
@@ -602,6 +632,8 @@ def test_randomised_configurations_against_the_oracle(dev, monkeypatch):
         if mode != "none":
             af = rng.random(n_var) * rng.choice([1.0, 1e-3])
             af[rng.random(n_var) < 0.05] = 0.0
+            if rng.random() < 0.25:                                             # too wide for a lossless unit: coarse one
+                af[rng.random(n_var) < 0.3] *= 1e-25
             af = af.astype(np.float32) if mode == "f32" else af
         chunks = None
         if n_var > 200 and rng.random() < 0.5:

@@ -9,6 +9,9 @@
 //   float32 AF: E = exact integer sum of AF*2^q.  While E < 2^53 every partial sum of the reference
 //               is exact, hence reference == E (B = 0).  Beyond: B = n * 2^-53 * E (n addends).
 //   float64 AF: E sums the float32-rounded values exactly: B = (2^-24 + n * 2^-53) * E.
+//   Coarse unit (af_trunc: the table's mass times 2^q would overflow int64 at the lossless q): every addend is
+//               floored to the unit, so the exact sum of the float32 values lies in [E, E + n) units; the
+//               bounds above are then taken on that interval's ends, and nothing counts as exact.
 // k_cand keeps the samples whose weighted interval reaches the best lower bound -- only they can be
 // the argmax -- and k_chain recomputes exactly those few with the reference's sequential chain.
 // Result: bit-identical winner and score, with the bulk of the work order independent.
@@ -18,15 +21,16 @@ __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c
 {
     const i64 e = a.afsum[s];
     est = (double)e * a.af_scale;
-    double bound;
+    const double top = a.af_trunc ? est + (double)c * a.af_scale : est;  // upper end of the exact float32 sum
+    double rel;
     if (a.af_is_f64) {
         exact = c == 0;
-        bound = exact ? 0.0 : 1.02 * (5.9604644775390625e-08 + (double)c * 1.1102230246251565e-16) * est;
+        rel = 1.02 * (5.9604644775390625e-08 + (double)c * 1.1102230246251565e-16);
     } else {
-        exact = e < (1ll << 53);
-        bound = exact ? 0.0 : 1.05 * ((double)c * 1.1102230246251565e-16 * est + 1.2e-16 * est);
+        exact = (e < (1ll << 53) && !a.af_trunc) || c == 0;
+        rel = 1.05 * ((double)c * 1.1102230246251565e-16 + 1.2e-16);
     }
-    double l = est - bound, h = est + bound;
+    double l = exact ? est : est - rel * est, h = exact ? est : top + rel * top;
     if (l < 0.0) l = 0.0;
     if (a.weights) {
         const double w = a.weights[a.first + s];
@@ -42,11 +46,11 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
 {
     __shared__ double wmax[4];
     __shared__ unsigned n_c;
-    __shared__ int inexact, any_inexact;
+    __shared__ int inexact, any_inexact, zero_est;
     IterState *st = a.st;
     if (st->done) return;
     const unsigned n_active = st->n_active;
-    if (threadIdx.x == 0) { n_c = 0; inexact = 0; any_inexact = 0; }
+    if (threadIdx.x == 0) { n_c = 0; inexact = 0; any_inexact = 0; zero_est = 0; }
     double best_lo = -__builtin_inf();
     for (unsigned i = threadIdx.x; i < n_active; i += 256) {
         const unsigned s = a.act[i];
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
                 a.cand->val[slot] = est;
             }
             if (!exact) inexact = 1;
+            if (!exact && est == 0.0) zero_est = 1;  // coarse unit: every addend floored away, yet the true score is > 0
         }
     }
     __syncthreads();
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
         st->cand_overflow = n_c > UTM_MAX_CAND;
         // one candidate only: the argmax is settled (its estimate is also the largest); its exact float64 sum is
         // needed just for the reported score, which the caller may not want
-        st->need_chain = inexact && !(a.af_skip_single && n_c == 1);
+        // (... unless its estimate is 0 while it has addends: the stop rule compares the score with 0, select.py:51)
+        st->need_chain = inexact && (zero_est || !(a.af_skip_single && n_c == 1));
         st->all_exact = !any_inexact;
     }
 }

@@ -100,6 +100,7 @@ struct PickArgs {
     Mailbox *const *peer_mbox; // every shard's mailbox base, as mapped here (index = rank)
     CandBuf *cand;   // verified-parallel AF: candidate list, else nullptr
     int af_is_f64;   // the estimate sums float32-rounded values of float64 AFs
+    int af_trunc;    // the fixed-point unit is coarser than the smallest AF's last bit: every addend may lose < 1 unit
     int af_skip_single;  // a single candidate is the winner whatever its exact sum is: skip its chain, report the estimate
     Rec *recs;       // exchange slot headers: recs[r] at xbuf + r*slot_words
     u64 slot_words;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_newly_mask(u64 *__restrict__ covered, c
 
 template <bool AF>
 __global__ __launch_bounds__(256) void k_decr(const u64 *__restrict__ cols, u64 wp, const unsigned *__restrict__ afbits,
-                                              int e_base, const IterState *__restrict__ st,
+                                              const IterState *__restrict__ st,
                                               const unsigned *__restrict__ act, const unsigned *__restrict__ list_idx,
                                               const u64 *__restrict__ list_val, const unsigned *__restrict__ list_n,
                                               u64 *__restrict__ cnt, i64 *__restrict__ afsum)
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_decr(const u64 *__restrict__ cols, u64 
         if (AF) {
             const unsigned *a = afbits + (u64)w * 64;
             while (x) {
-                dsum += af_fixed(a[__builtin_ctzll(x)], e_base);
+                dsum += af_fixed(a[__builtin_ctzll(x)]);
                 x &= x - 1;
             }
         }
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_interleave(const u64 *__restrict__ cols
 #define UTM_DECR_STAGE 32  // listed words per LDS stage
 template <bool AF>
 __global__ __launch_bounds__(256) void k_decr_t(const u64 *__restrict__ rows_t, u64 s_t, const unsigned *__restrict__ afbits,
-                                                int e_base, const IterState *__restrict__ st,
+                                                const IterState *__restrict__ st,
                                                 const unsigned char *__restrict__ state, unsigned n_local,
                                                 const unsigned *__restrict__ list_idx, const u64 *__restrict__ list_val,
                                                 const unsigned *__restrict__ list_n, u64 *__restrict__ cnt,
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_decr_t(const u64 *__restrict__ rows_t, 
                 for (int k = 0; k < 4; ++k) {
                     dec += __popcll(x[k]);
                     while (x[k]) {
-                        dsum += af_fixed(af_l[j + k][__builtin_ctzll(x[k])], e_base);
+                        dsum += af_fixed(af_l[j + k][__builtin_ctzll(x[k])]);
                         x[k] &= x[k] - 1;
                     }
                 }

@@ -79,7 +79,7 @@ static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
     n_groups = (a_ub + group - 1) / group;
     LaunchTimer t(c);
     hipExtLaunchKernelGGL(k_score_afq, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,
-                          ch.covered, ch.wp, ch.af32, 150 - c->af_q, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,
+                          ch.covered, ch.wp, ch.afx, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,
                           group, n_groups);
 }
 
@@ -115,11 +115,10 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
     const unsigned blocks = (unsigned)round_up(tiles * n_groups, 8);  // XCD-aware map: tile_of_block()
     LaunchTimer t(c);
     if (af) {
-        const unsigned *afb = reinterpret_cast<const unsigned *>(ch.af32);
-        const int eb = 150 - c->af_q;
+        const unsigned *afb = ch.afx;
 #define UTM_LAUNCH_AFS(S, Q)                                                                                              \
     hipExtLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,       \
-                          ch.covered, ch.wp, afb, eb, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,   \
+                          ch.covered, ch.wp, afb, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,   \
                           (unsigned)group, n_groups, delta ? ch.mask : nullptr)
         if (steps == 32) UTM_LAUNCH_AFS(32, 8);  // second argument: queue depth per lane
         else if (steps == 16) UTM_LAUNCH_AFS(16, 16);
@@ -184,26 +183,25 @@ static int enqueue_score_decr(utm_ctx *c)
         Chunk &ch = c->chunks[k];
         hipLaunchKernelGGL(k_newly, dim3((unsigned)std::min<u64>(1024, (ch.wp / 2 + 511) / 512)), dim3(512), 0, c->stream, ch.covered,
                            ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, ch.list_idx, ch.list_val, c->d_listn + k);
-        const unsigned *afbits = af ? reinterpret_cast<const unsigned *>(ch.af32) : nullptr;
-        const int e_base = af ? 150 - c->af_q : 0;
+        const unsigned *afbits = af ? ch.afx : nullptr;
         u64 *cnt = af ? c->d_cnt : c->d_cnt_keep;
         i64 *afsum = af ? c->d_afsum : c->d_afsum_keep;
         if (c->decr_interleaved) {
             const dim3 grid((unsigned)((s_t + 255) / 256), slices);
             if (af)
-                hipLaunchKernelGGL(k_decr_t<true>, grid, dim3(256), 0, c->stream, ch.rows_t, s_t, afbits, e_base, c->d_st, c->d_state,
+                hipLaunchKernelGGL(k_decr_t<true>, grid, dim3(256), 0, c->stream, ch.rows_t, s_t, afbits, c->d_st, c->d_state,
                                    c->n_local, ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
             else
-                hipLaunchKernelGGL(k_decr_t<false>, grid, dim3(256), 0, c->stream, ch.rows_t, s_t, afbits, e_base, c->d_st, c->d_state,
+                hipLaunchKernelGGL(k_decr_t<false>, grid, dim3(256), 0, c->stream, ch.rows_t, s_t, afbits, c->d_st, c->d_state,
                                    c->n_local, ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
             continue;
         }
         const dim3 grid((a_ub + 3) / 4, split);
         if (af)
-            hipLaunchKernelGGL(k_decr<true>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, afbits, e_base, c->d_st, c->d_act,
+            hipLaunchKernelGGL(k_decr<true>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, afbits, c->d_st, c->d_act,
                                ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
         else
-            hipLaunchKernelGGL(k_decr<false>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, afbits, e_base, c->d_st, c->d_act,
+            hipLaunchKernelGGL(k_decr<false>, grid, dim3(256), 0, c->stream, ch.cols, ch.wp, afbits, c->d_st, c->d_act,
                                ch.list_idx, ch.list_val, c->d_listn + k, cnt, afsum);
     }
     HIP_TRY(hipGetLastError());
@@ -459,7 +457,7 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->loop_ms = c->loop_ms;
     out->algo_bytes = c->algo_bytes;
     out->af_mode = c->af_mode;
-    out->af_fixed_point = c->af_fixed;
+    out->af_fixed_point = c->af_fixed ? (c->af_trunc ? 2 : 1) : 0;
     out->af_q = c->af_q;
     out->n_chunks = (int32_t)c->chunks.size();
     out->decr_iterations = c->decr_iterations;

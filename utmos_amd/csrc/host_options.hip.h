@@ -88,8 +88,10 @@ static int build_af_tables(utm_ctx *c)
     for (auto &ch : c->chunks) {
         if ((void *)ch.af32 != ch.af) (void)hipFree(ch.af32);
         (void)hipFree(ch.af);
+        (void)hipFree(ch.afx);
         ch.af = nullptr;
         ch.af32 = nullptr;
+        ch.afx = nullptr;
     }
     (void)hipFree(c->d_seq);
     c->d_seq = nullptr;
@@ -121,21 +123,51 @@ static int build_af_tables(utm_ctx *c)
         }
     }
     if (e_min == 1000) e_min = e_max = 0;
-    // Every float32 a > 0 is m * 2^(e-23), m < 2^24: a multiple of 2^-q for q = 23 - e_min.  The
-    // estimate kernel sums a * 2^q = m << (e - e_min) as int64: needs q >= 0 and mass * 2^q < 2^62.
-    const int q = 23 - e_min;
-    if (!(c->flags & UTM_FLAG_AF_SEQUENTIAL) && representable && q >= 0 && q <= 149 &&
-        e_max - e_min <= 38 && mass * ldexpl(1.0L, q - 62) < 1.0L) {
+    // Every float32 a > 0 is m * 2^(e-23), m < 2^24: a multiple of 2^-q for q = 23 - e_min.  The estimate kernels
+    // sum floor(a * 2^q) as int64.  Lossless q when the whole table's mass fits (mass * 2^q < 2^62) and the largest
+    // value's mantissa can be shifted into place (q <= 61 - e_max): true for real allele frequencies (>= 1/2S).
+    // Otherwise the largest q that fits: small values lose their low bits (< 1 unit per addend), which the interval
+    // arithmetic of the verification accounts for -- slower candidates, same rows, and no cliff to the sequential
+    // kernel for an unusual table.
+    c->af_trunc = false;
+    int q = 23 - e_min;
+    if (mass > 0) {
+        int q_mass = 61;
+        while (q_mass >= 0 && !(mass * ldexpl(1.0L, q_mass - 62) < 1.0L)) --q_mass;
+        const int q_fit = std::min(q_mass, 61 - e_max);
+        if (q > q_fit) {
+            q = q_fit;
+            c->af_trunc = true;
+        }
+    }
+    if (!(c->flags & UTM_FLAG_AF_SEQUENTIAL) && representable && q >= 0 && q <= 149) {
         c->af_fixed = true;
         c->af_q = q;
+    } else {
+        c->af_trunc = false;
     }
     std::vector<SeqChunk> seq;
     for (size_t k = 0; k < c->chunks.size(); ++k) {
         Chunk &ch = c->chunks[k];
         const size_t n = ch.wp * 64;
-        HIP_TRY(hipMalloc(&ch.af32, n * 4));
-        HIP_TRY(copy_sync(c, ch.af32, v32[k].data(), n * 4, hipMemcpyHostToDevice));
+        if (c->af_fixed) {
+            // the estimate's table: floor(a * 2^q) as mantissa << shift (af_fixed(), score_af.hip.h)
+            std::vector<unsigned> fx(n, 0u);
+            const int e_base = 150 - c->af_q;
+            for (u64 v = 0; v < ch.n_var; ++v) {
+                unsigned bits;
+                memcpy(&bits, &v32[k][v], 4);
+                if ((bits & 0x7FFFFFFFu) == 0) continue;  // AF == 0: its row is cleared anyway
+                const unsigned m = (bits & 0x7FFFFFu) | 0x800000u;
+                const int sh = (int)(bits >> 23) - e_base;
+                fx[v] = sh >= 0 ? ((unsigned)sh << 24) | m : (sh > -24 ? m >> -sh : 0u);
+            }
+            HIP_TRY(hipMalloc(&ch.afx, n * 4));
+            HIP_TRY(copy_sync(c, ch.afx, fx.data(), n * 4, hipMemcpyHostToDevice));
+        }
         if (c->af_mode == UTM_AF_F32) {
+            HIP_TRY(hipMalloc(&ch.af32, n * 4));
+            HIP_TRY(copy_sync(c, ch.af32, v32[k].data(), n * 4, hipMemcpyHostToDevice));
             ch.af = ch.af32;
         } else {
             HIP_TRY(hipMalloc(&ch.af, n * 8));

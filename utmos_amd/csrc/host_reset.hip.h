@@ -180,6 +180,7 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     a.peer_mbox = c->d_peer_mbox;
     a.cand = (c->af_mode != UTM_AF_NONE && c->af_fixed && !c->af_all_exact) ? c->d_cand : nullptr;
     a.af_is_f64 = c->af_mode == UTM_AF_F64;
+    a.af_trunc = c->af_trunc ? 1 : 0;
     // (a shard's record is compared with other shards' records: there the score has to be exact)
     a.af_skip_single = (!c->af_exact_scores && c->n_local == c->n_total) ? 1 : 0;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);

@@ -2,6 +2,16 @@
 #pragma once
 #include "score_int.hip.h"
 
+// Fixed-point AF table entry (built by the host, host_options.hip.h): [31:24] shift, [23:0] mantissa -- the value
+// floor(AF * 2^q) = mantissa << shift as int64.  At the lossless q (the usual case) the mantissa is the float32's 24
+// bits and the shift its exponent above the unit; a table whose mass would overflow int64 there gets a coarser unit
+// and its small values arrive already floored (shift 0) -- the interval arithmetic of af_verify.hip.h accounts for
+// the < 1 unit each addend may lose.  Two VALU ops per set bit.
+__device__ __forceinline__ u64 af_fixed(unsigned f)
+{
+    return (u64)(f & 0xFFFFFFu) << (f >> 24);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1-AF (float32 AF as exact fixed point): besides the count, afsum[s] += the
 // sum of AF[v] * 2^q as int64 over the set, uncovered bits.  Tile = 8192 variants = one KiB of every
@@ -9,17 +19,17 @@
 // in flight, skips samples whose KiB has no surviving bit (the common case once coverage has grown),
 // otherwise walks the bits (ctz / clear-lowest / ds_read_b32 gather / mantissa << exponent / 64-bit add).
 // A float32 a = m * 2^(e-150) (m = 24-bit mantissa with the hidden bit, e = biased exponent), so
-// a * 2^q = m << (e - e_base), e_base = 150 - q >= the smallest exponent present (host checks).
+// a * 2^q = af_fixed(table entry).
 // ------------------------------------------------------------------------------------------------
 #define UTM_AF_TILE_WORDS 128
 __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
-                                                   const float *__restrict__ af, int e_base,
+                                                   const unsigned *__restrict__ af,
                                                    const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
                                                    unsigned n_groups)
 {
-    __shared__ unsigned aft[UTM_AF_TILE_WORDS * 64];  // float32 bit patterns
+    __shared__ unsigned aft[UTM_AF_TILE_WORDS * 64];  // fixed-point table entries
     __shared__ u64 live[UTM_AF_TILE_WORDS];
     if (st->done) return;
     unsigned tile, grp;
@@ -69,12 +79,12 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
             while (b0) {
                 const unsigned bits = a0[__builtin_ctzll(b0)];
                 b0 &= b0 - 1;
-                sum += (u64)((bits & 0x7FFFFFu) | 0x800000u) << ((bits >> 23) - e_base);
+                sum += af_fixed(bits);
             }
             while (b1) {
                 const unsigned bits = a1[__builtin_ctzll(b1)];
                 b1 &= b1 - 1;
-                sum += (u64)((bits & 0x7FFFFFu) | 0x800000u) << ((bits >> 23) - e_base);
+                sum += af_fixed(bits);
             }
             const unsigned n = wave_sum_u32(n_lane);
             const i64 total = wave_sum_u63(sum);  // per lane < 2^53 (the host's exactness precondition)
@@ -97,11 +107,6 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 // UTM_AF_SWITCH.  Same integer sums, same exactness argument.
 // ------------------------------------------------------------------------------------------------
 // queue entries per wave: STEPS KiB of ~covered + 4 queues must leave room for 4-5 workgroups per CU
-__device__ __forceinline__ u64 af_fixed(unsigned f, int e_base)
-{
-    return (u64)((f & 0x7FFFFFu) | 0x800000u) << ((f >> 23) - e_base);
-}
-
 // CAP = queue depth per LANE: every lane keeps its own little queue (slot-major in LDS, so a wave's
 // pushes are conflict free) -- no cross-lane prefix sum is needed to place an entry.
 // delta_mask == nullptr: full scoring against ~covered (adds to the accumulators, fuses the pending update).
@@ -110,7 +115,7 @@ __device__ __forceinline__ u64 af_fixed(unsigned f, int e_base)
 // accumulators.  Same bytes streamed, but only the few newly covered bits take the queue/gather path.
 template <int STEPS, int CAP>
 __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
-                                                   const unsigned *__restrict__ afbits, int e_base, const Pending pend,
+                                                   const unsigned *__restrict__ afbits, const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
                                                    unsigned n_groups, const u64 *__restrict__ delta_mask)
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
             for (unsigned j = 0; __ballot(j < qc) != 0; j += 2) {  // two independent gathers per round
                 const unsigned f0 = j < qc ? af_tile[q[j][lane]] : 0u;
                 const unsigned f1 = j + 1 < qc ? af_tile[q[j + 1][lane]] : 0u;
-                if (j < qc) sum += af_fixed(f0, e_base);
-                if (j + 1 < qc) sum += af_fixed(f1, e_base);
+                if (j < qc) sum += af_fixed(f0);
+                if (j + 1 < qc) sum += af_fixed(f1);
             }
             qc = 0;
         };
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
                         unsigned bits = b[u][d];
                         const unsigned v0 = base + u * (UTM_STEP_WORDS * 64) + d * 32;
                         while (bits) {
-                            sum += af_fixed(af_tile[v0 + __builtin_ctz(bits)], e_base);
+                            sum += af_fixed(af_tile[v0 + __builtin_ctz(bits)]);
                             bits &= bits - 1;
                         }
                     }

@@ -113,7 +113,8 @@ struct Chunk {
     u64 *cols = nullptr;
     u64 *covered = nullptr;
     void *af = nullptr;    // device: AF in its own type (float or double), wp*64 entries: chains read this
-    float *af32 = nullptr; // device: float32 AF for the parallel estimate (== af when the AF is float32)
+    float *af32 = nullptr; // device: float32 AF (== af when the AF is float32; float64 AF: not kept)
+    unsigned *afx = nullptr;  // device: fixed-point table of the parallel estimate, wp*64 entries (af_fixed())
     int index = 0;
     const u64 **d_peer_cols = nullptr;  // device array [n_ranks]: this chunk's column base on every rank (P2P), or null
     std::vector<void *> ipc_opened;     // mappings to close
@@ -173,6 +174,7 @@ struct utm_ctx {
     bool have_weights = false;
     int af_mode = UTM_AF_NONE;
     bool af_fixed = false;  // AF runs as the verified-parallel scheme (exact fixed-point estimate + chains)
+    bool af_trunc = false;  // ... with a unit coarser than the smallest AF's last mantissa bit (addends lose < 1 unit each)
     int af_q = 0;
     bool prepared = false;  // device loop state matches h_state / AF tables
     bool dirty_tables = true;
@@ -284,6 +286,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
         (void)hipFree(ch.cols);
         (void)hipFree(ch.covered);
         if ((void *)ch.af32 != ch.af) (void)hipFree(ch.af32);
+        (void)hipFree(ch.afx);
         (void)hipFree(ch.af);
         (void)hipFree(ch.list_idx);
         (void)hipFree(ch.rows_t);
