@@ -580,6 +580,32 @@ def test_parity_at_production_tile_sizes(dev):
         assert got[0].tolist() == exp[0].tolist() and got[2].tolist() == exp[2].tolist()
 
 
+def test_parity_with_many_samples(dev):
+    """100,000 samples (configs[3]'s sample count) x 150k variants: many groups per tile, a 100k-entry active list,
+    25 pick rounds per thread -- first iterations of the integer, weighted and decremental loops against the OpenMP
+    C oracle on the matrix downloaded from the device."""
+    n_var, n_samp, k = 150_000, 100_000, 12
+    rng = np.random.default_rng(77)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.synth_fill(c, seed=3)
+        cols = m.download_columns(c)
+        state = np.ones(n_samp, np.uint8)
+        state[rng.choice(n_samp, 500, replace=False)] = 2
+        m.set_state(state)
+        got = m.run(k)
+        exp = ou.c_greedy(cols, n_var, state, k_max=k, omp=True)
+        assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+        w = rng.choice([0.5, 1.0, 1.0, 2.0], n_samp)
+        m.set_weights(w)
+        m.set_decremental(True, 1.0)
+        m.reset()
+        got = m.run(k)
+        exp = ou.c_greedy(cols, n_var, state, w, k_max=k, omp=True)
+        assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+        assert m.stats()["decr_iterations"] > 0
+
+
 @pytest.mark.parametrize("decremental", [False, True])
 def test_full_size_select_all_invariants(dev, decremental):
     """BASELINE configs[1] in full (10M x 2,504, select all): size-independent properties of a greedy
