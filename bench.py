@@ -180,6 +180,10 @@ def main():
                              "--nproc-per-node N (see module docstring)")
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > 1:
+        # a rank that lost its peers must not sit in a collective forever: say where it was and leave
+        import faulthandler
+        faulthandler.dump_traceback_later(900, exit=True)
 
     import numpy as np
     from utmos_amd import device
