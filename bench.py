@@ -235,7 +235,8 @@ def main():
         replica = m.stats()["p2p_replica_bytes"]
         columns = (f"winner columns read from a one-time local copy of the other shards' columns ({replica / 1e9:.2f} GB)"
                    if replica else "in-place column reads over hipIpc mappings (xGMI)")
-        exchange = f"device mailboxes + {columns}" if m.fused_mailboxes else (
+        boxes = "host shared-memory mailboxes" if getattr(m, "host_mailboxes", False) else "device mailboxes"
+        exchange = f"{boxes} + {columns}" if m.fused_mailboxes else (
             "host-staged: records over TCP, winner column " + (columns if m.p2p else "through host memory")
             if host_staged else
             f"ncclAllGather of records, {columns}" if m.p2p else "ncclAllGather of records + columns")

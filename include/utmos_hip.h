@@ -186,6 +186,12 @@ int utm_p2p_import(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *blob
  * is then collective over the shards exactly like after utm_comm_init. */
 int utm_p2p_selftest(utm_ctx *ctx, int32_t *ok);
 int utm_p2p_use_mailboxes(utm_ctx *ctx, int32_t on);
+/* (new) Record mailboxes in host memory shared by the shards' processes -- the fallback when the device-memory
+ * mailboxes cannot be exported or fail the self-test: `shared` is the same zero-filled region (e.g. a POSIX
+ * shared-memory mapping) in every shard, utm_p2p_host_mailbox_bytes(n_ranks) long; it is page-locked and mapped
+ * for the GPU here and released by utm_ctx_destroy.  Follow with utm_p2p_selftest / utm_p2p_use_mailboxes. */
+int utm_p2p_host_mailbox_bytes(int32_t n_ranks, uint64_t *n_bytes);
+int utm_p2p_host_mailboxes(utm_ctx *ctx, void *shared, uint64_t n_bytes);
 
 /* ---- RCCL (one process per GPU; ids are exchanged by the caller) ------------------------------ */
 #define UTM_UNIQUE_ID_BYTES 128

@@ -442,24 +442,28 @@ def _gpu_fused_worker(rank, world, port, q):
             exp = ou.c_greedy(cols, n_var, state, w, af=a)
             ok = ok and got[0] == exp[0].tolist() and got[1] == exp[1].tolist() and got[2] == exp[2].tolist()
         ok = ok and (replica > 0) == (os.environ.get("UTM_P2P_REPLICATE", "1") != "0")
-        q.put((rank, ok, len(out["int"][0]), f"fused={fused} replica={replica}"))
+        ok = ok and getattr(m, "host_mailboxes", False) == (os.environ.get("UTM_MBOX") == "host")
+        q.put((rank, ok, len(out["int"][0]), f"fused={fused} replica={replica} host_mailboxes={getattr(m, 'host_mailboxes', False)}"))
     except BaseException as e:  # noqa: BLE001
         q.put((rank, False, 0, repr(e)))
     finally:
         transport.close()
 
 
-@pytest.mark.parametrize("columns", ["replicated", "in-place"])
+@pytest.mark.parametrize("columns", ["replicated", "in-place", "replicated+host-mailboxes"])
 def test_fused_device_side_exchange_three_processes(dev, columns, monkeypatch):
     """The production multi-shard loop without RCCL in it: records through hipIpc-mapped mailboxes, winner
     columns read from the one-time local copy of the peers' columns (or in place through the mappings, what a
     matrix too large to replicate runs), utm_run collective over three processes (sharing the box's one GPU)."""
     import multiprocessing as mp
     import os
-    monkeypatch.setenv("UTM_P2P_REPLICATE", "1" if columns == "replicated" else "0")
+    monkeypatch.setenv("UTM_P2P_REPLICATE", "0" if columns == "in-place" else "1")
+    # third case: the record mailboxes live in host shared memory (what runs when the device-memory ones cannot be
+    # exported or fail their self-test)
+    monkeypatch.setenv("UTM_MBOX", "host" if columns.endswith("host-mailboxes") else "device")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 39500 + os.getpid() % 2000 + (0 if columns == "replicated" else 2000)
+    port = 39500 + os.getpid() % 2000 + {"replicated": 0, "in-place": 2000}.get(columns, 4000)
     procs = [ctx.Process(target=_gpu_fused_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()

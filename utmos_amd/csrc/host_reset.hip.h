@@ -176,7 +176,7 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     a.fscore = c->af_mode != UTM_AF_NONE ? c->d_fscore : nullptr;  // sequential scores (fallback / overflow)
     a.af_scale = ldexp(1.0, -c->af_q);
     // float32 AF sums only shrink: once every estimate was exact (< 2^53 units) the plain exact pick suffices
-    a.mbox = c->d_mbox;
+    a.mbox = c->mbox_local;
     a.peer_mbox = c->d_peer_mbox;
     a.cand = (c->af_mode != UTM_AF_NONE && c->af_fixed && !c->af_all_exact) ? c->d_cand : nullptr;
     a.af_is_f64 = c->af_mode == UTM_AF_F64;

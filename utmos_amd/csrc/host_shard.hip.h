@@ -185,6 +185,7 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
         }
         if (r == rank) {
             boxes[r] = c->d_mbox;
+            c->mbox_local = c->d_mbox;
         } else if (hd.has_mbox && all_boxes) {
             void *p = nullptr;
             if (hipIpcOpenMemHandle(&p, hs[c->chunks.size()], hipIpcMemLazyEnablePeerAccess) == hipSuccess) {
@@ -274,7 +275,7 @@ extern "C" int utm_p2p_selftest(utm_ctx *c, int32_t *ok)
     HIP_TRY(copy_sync(c, d_ok, &one, 4, hipMemcpyHostToDevice));
     for (int round = 0; round < 4; ++round) {
         c->xseq_host += 1;
-        hipLaunchKernelGGL(k_mbox_ping, dim3(1), dim3(64), 0, c->stream, c->d_mbox, c->d_peer_mbox, c->rank, c->n_ranks,
+        hipLaunchKernelGGL(k_mbox_ping, dim3(1), dim3(64), 0, c->stream, c->mbox_local, c->d_peer_mbox, c->rank, c->n_ranks,
                            c->xseq_host, d_ok);
     }
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -284,6 +285,43 @@ extern "C" int utm_p2p_selftest(utm_ctx *c, int32_t *ok)
     if (e != hipSuccess) return fail(UTM_EHIP, "mailbox self-test: %s", hipGetErrorString(e));
     *ok = got;
     c->prepared = false;  // the loop state carries the exchange sequence number
+    return UTM_OK;
+}
+
+// Record mailboxes in HOST memory shared by the shards' processes (a POSIX shared-memory mapping the caller made):
+// the fallback when the device-memory mailboxes cannot be exported or do not pass the self-test.  Every GPU posts
+// and polls over PCIe instead of xGMI -- a few microseconds per exchange, still far below a collective's launch.
+// `shared` must be zero-filled, the same region in every shard, at least utm_p2p_host_mailbox_bytes(n_ranks) long.
+extern "C" int utm_p2p_host_mailbox_bytes(int32_t n_ranks, uint64_t *n_bytes)
+{
+    if (!n_bytes || n_ranks < 1 || n_ranks > UTM_MAX_RANKS) return fail(UTM_EINVAL, "bad arguments");
+    *n_bytes = (uint64_t)n_ranks * 2 * n_ranks * sizeof(Mailbox);
+    return UTM_OK;
+}
+
+extern "C" int utm_p2p_host_mailboxes(utm_ctx *c, void *shared, uint64_t n_bytes)
+{
+    CTX(c);
+    if (!c->p2p) return fail(UTM_ESTATE, "map the shards' columns first (utm_p2p_import)");
+    const u64 per_rank = (u64)2 * c->n_ranks;  // slots [seq & 1][source] of one shard
+    if (!shared || n_bytes < (u64)c->n_ranks * per_rank * sizeof(Mailbox)) return fail(UTM_EINVAL, "shared region too small");
+    if (c->mbox_host) {
+        (void)hipHostUnregister(c->mbox_host);
+        c->mbox_host = nullptr;
+    }
+    HIP_TRY(hipHostRegister(shared, n_bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    c->mbox_host = shared;
+    void *dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dev, shared, 0));
+    std::vector<Mailbox *> boxes(c->n_ranks);
+    for (int r = 0; r < c->n_ranks; ++r) boxes[r] = static_cast<Mailbox *>(dev) + (u64)r * per_rank;
+    (void)hipFree(c->d_peer_mbox);
+    c->d_peer_mbox = nullptr;
+    HIP_TRY(hipMalloc(&c->d_peer_mbox, (size_t)c->n_ranks * sizeof(Mailbox *)));
+    HIP_TRY(copy_sync(c, c->d_peer_mbox, boxes.data(), (size_t)c->n_ranks * sizeof(Mailbox *), hipMemcpyHostToDevice));
+    c->mbox_local = boxes[c->rank];
+    c->mbox_ok = false;  // self-test and agree again before use
+    c->prepared = false;
     return UTM_OK;
 }
 

@@ -201,6 +201,8 @@ struct utm_ctx {
     Mailbox *d_mbox = nullptr;           // local slots [2][UTM_MAX_RANKS], uncached device memory, exported to the peers
     Mailbox **d_peer_mbox = nullptr;     // device array [n_ranks] of mapped mailbox bases
     std::vector<void *> mbox_opened;
+    Mailbox *mbox_local = nullptr;       // the slots this shard polls: d_mbox, or its part of a host shared-memory region
+    void *mbox_host = nullptr;           // registered host region (utm_p2p_host_mailboxes), unregistered at destroy
     bool mbox_ok = false;                // every shard passed the mailbox self-test: utm_run exchanges through them
     u64 xseq_host = 0;                   // exchanges completed so far (self-test rounds included)
 
@@ -280,6 +282,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     p2p_close(c);
+    if (c->mbox_host) (void)hipHostUnregister(c->mbox_host);
     (void)hipFree(c->d_mbox);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto &ch : c->chunks) {

@@ -216,6 +216,19 @@ class DeviceMatrix:
         nat.check(nat.lib().utm_p2p_selftest(self._h, ctypes.byref(ok)))
         return bool(ok.value)
 
+    @staticmethod
+    def p2p_host_mailbox_bytes(n_ranks):
+        n = ctypes.c_uint64()
+        nat.check(nat.lib().utm_p2p_host_mailbox_bytes(int(n_ranks), ctypes.byref(n)))
+        return n.value
+
+    def p2p_host_mailboxes(self, shared):
+        """shared: a writable buffer (mmap of a shared-memory file) every shard maps; kept alive with the matrix."""
+        view = (ctypes.c_char * len(shared)).from_buffer(shared)
+        nat.check(nat.lib().utm_p2p_host_mailboxes(self._h, ctypes.addressof(view), len(shared)))
+        self._host_mailboxes = (shared, view)
+        self.host_mailboxes = True
+
     def p2p_use_mailboxes(self, on=True):
         """After every shard's self-test passed: run() becomes collective, records travel through the mailboxes."""
         nat.check(nat.lib().utm_p2p_use_mailboxes(self._h, 1 if on else 0))

@@ -248,10 +248,50 @@ def enable_p2p(shard, transport):
         shard.p2p = False   # (a context that imported keeps its mappings but columns are broadcast again)
         return False
     # the mappings exist everywhere: can the shards also exchange their records on the device?
-    boxes = shard.p2p_selftest()
+    import os
+    boxes = shard.p2p_selftest() if os.environ.get("UTM_MBOX", "device") != "host" else False
     if all(r[1] == 1 for r in transport.allgather((0.0, 1 if boxes else 0, 0))):
         shard.p2p_use_mailboxes(True)   # shard.fused: run() is now collective, nothing goes through the host
+    elif _host_mailboxes(shard, transport):
+        shard.p2p_use_mailboxes(True)   # same loop, the 64-byte records cross PCIe instead of xGMI
     return True
+
+
+def _host_mailboxes(shard, transport):
+    """Fallback for the record exchange: mailboxes in a POSIX shared-memory file mapped by every shard's process and
+    page-locked for its GPU.  Collective; True when every shard passed the self-test through them."""
+    import mmap
+    import os
+    size = shard.p2p_host_mailbox_bytes(transport.world)
+    size = (size + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE
+    name = b""
+    if transport.rank == 0:
+        path = f"/dev/shm/utmos_amd_mbox_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little')}"
+        try:
+            with open(path, "wb") as fh:
+                fh.truncate(size)        # zero-filled
+            name = path.encode()
+        except OSError:
+            name = b""
+    name = transport.allgather_bytes(name.ljust(96, b"\0"))[0].rstrip(b"\0").decode()
+    ok = bool(name)
+    if ok:
+        try:
+            with open(name, "r+b") as fh:
+                shared = mmap.mmap(fh.fileno(), size)
+            shard.p2p_host_mailboxes(shared)
+        except Exception:  # noqa: BLE001 - any failure means "not here"
+            ok = False
+    everyone = all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0)))   # also: everybody has it open
+    if transport.rank == 0 and name:
+        try:
+            os.unlink(name)              # the mappings keep it alive
+        except OSError:
+            pass
+    if not everyone:
+        return False
+    boxes = shard.p2p_selftest()
+    return all(r[1] == 1 for r in transport.allgather((0.0, 1 if boxes else 0, 0)))
 
 
 def sharded_greedy(shard, transport, select_count):
