@@ -353,7 +353,7 @@ def main():
     value = iters / elapsed
     whole_loop_gbps = algo_bytes_step * world * args.steps / elapsed / 1e9   # shards are equal-sized to within one sample
     line = {
-        "metric": "greedy iterations/sec + achieved HBM GB/s, 10M variants x 2.5k samples",
+        "metric": "greedy iterations/sec + achieved HBM GB/s, 10M variants \u00d7 2.5k samples",   # BASELINE.json's string
         "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": (args.af_dtype + "+u64") if args.af else "u64", "data": "synthetic",
