@@ -192,6 +192,12 @@ int utm_p2p_use_mailboxes(utm_ctx *ctx, int32_t on);
  * for the GPU here and released by utm_ctx_destroy.  Follow with utm_p2p_selftest / utm_p2p_use_mailboxes. */
 int utm_p2p_host_mailbox_bytes(int32_t n_ranks, uint64_t *n_bytes);
 int utm_p2p_host_mailboxes(utm_ctx *ctx, void *shared, uint64_t n_bytes);
+/* (new) utm_p2p_import's end state without hipIpc, for nodes where device memory cannot be shared between
+ * processes: chunk_cols[k] points to ALL n_total columns of chunk k in host memory (stride_words[k] words per
+ * column; e.g. a shared-memory file every shard wrote its own columns into), firsts / locals give every shard's
+ * sample range.  The other shards' columns are uploaded into a local copy; UTM_ENOMEM when that does not fit. */
+int utm_p2p_replica_from_host(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const uint32_t *firsts,
+                              const uint32_t *locals, const uint64_t *const *chunk_cols, const uint64_t *stride_words);
 
 /* ---- RCCL (one process per GPU; ids are exchanged by the caller) ------------------------------ */
 #define UTM_UNIQUE_ID_BYTES 128

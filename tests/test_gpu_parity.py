@@ -450,7 +450,7 @@ def _gpu_fused_worker(rank, world, port, q):
         transport.close()
 
 
-@pytest.mark.parametrize("columns", ["replicated", "in-place", "replicated+host-mailboxes"])
+@pytest.mark.parametrize("columns", ["replicated", "in-place", "replicated+host-mailboxes", "no-ipc:host-replica+host-mailboxes"])
 def test_fused_device_side_exchange_three_processes(dev, columns, monkeypatch):
     """The production multi-shard loop without RCCL in it: records through hipIpc-mapped mailboxes, winner
     columns read from the one-time local copy of the peers' columns (or in place through the mappings, what a
@@ -461,9 +461,11 @@ def test_fused_device_side_exchange_three_processes(dev, columns, monkeypatch):
     # third case: the record mailboxes live in host shared memory (what runs when the device-memory ones cannot be
     # exported or fail their self-test)
     monkeypatch.setenv("UTM_MBOX", "host" if columns.endswith("host-mailboxes") else "device")
+    # fourth case: no hipIpc at all -- the peers' columns reach the local copy through a host shared-memory file
+    monkeypatch.setenv("UTM_NO_IPC", "1" if columns.startswith("no-ipc") else "0")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 39500 + os.getpid() % 2000 + {"replicated": 0, "in-place": 2000}.get(columns, 4000)
+    port = 39500 + os.getpid() % 2000 + {"replicated": 0, "in-place": 2000, "replicated+host-mailboxes": 4000}.get(columns, 6000)
     procs = [ctx.Process(target=_gpu_fused_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()

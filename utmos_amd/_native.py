@@ -76,6 +76,7 @@ PROTOTYPES = {
     "utm_p2p_selftest": [_P, ctypes.POINTER(_I32)],
     "utm_p2p_host_mailbox_bytes": [_I32, ctypes.POINTER(_U64)],
     "utm_p2p_host_mailboxes": [_P, _P, _U64],
+    "utm_p2p_replica_from_host": [_P, _I32, _I32, _P, _P, _P, _P],
     "utm_p2p_use_mailboxes": [_P, _I32],
     "utm_comm_get_unique_id": [_P],
     "utm_comm_init": [_P, _I32, _I32, _P],

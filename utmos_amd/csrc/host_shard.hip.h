@@ -260,6 +260,68 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
     return UTM_OK;
 }
 
+// The same end state as utm_p2p_import + replication, without hipIpc: the caller gathered every shard's columns in
+// host memory (one array per chunk: n_total columns of `stride_words[k]` words, e.g. a shared-memory file each
+// shard's process wrote its own columns into); the other shards' columns are uploaded into a local copy and the
+// pending-column table points there.  For nodes where device memory cannot be shared between processes: the loop
+// then needs nothing but the record exchange (utm_p2p_host_mailboxes).  Fails with UTM_ENOMEM when the copy does
+// not fit -- the caller falls back to a collective that carries the columns.
+extern "C" int utm_p2p_replica_from_host(utm_ctx *c, int32_t rank, int32_t n_ranks, const uint32_t *firsts,
+                                         const uint32_t *locals, const uint64_t *const *chunk_cols,
+                                         const uint64_t *stride_words)
+{
+    CTX(c);
+    if (!firsts || !locals || !chunk_cols || !stride_words || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(UTM_EINVAL, "bad arguments");
+    if (n_ranks > UTM_MAX_RANKS) return fail(UTM_EINVAL, "at most %d shards", UTM_MAX_RANKS);
+    if (firsts[rank] != c->first || locals[rank] != c->n_local) return fail(UTM_EINVAL, "this shard's range differs from the table");
+    u64 covered_samples = 0;
+    for (int r = 0; r < n_ranks; ++r) covered_samples += locals[r];
+    if (covered_samples != c->n_total) return fail(UTM_EINVAL, "the shards' ranges do not add up to %u samples", c->n_total);
+    for (size_t k = 0; k < c->chunks.size(); ++k)
+        if (!chunk_cols[k] || stride_words[k] < c->chunks[k].w) return fail(UTM_EINVAL, "chunk %zu: no columns / stride too short", k);
+    p2p_close(c);
+    const u64 others = c->n_total - c->n_local;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if ((u64)free_b < others * c->col_words * 8 + (8ull << 30)) return fail(UTM_ENOMEM, "no room for a copy of the other shards' columns");
+    std::vector<std::vector<const u64 *>> table(c->chunks.size(), std::vector<const u64 *>(n_ranks, nullptr));
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        Chunk &ch = c->chunks[k];
+        if (others && hipMalloc(&ch.replica, (size_t)(others * ch.wp * 8)) != hipSuccess) {
+            (void)hipGetLastError();
+            p2p_close(c);
+            return fail(UTM_ENOMEM, "no room for a copy of the other shards' columns");
+        }
+        u64 off = 0;
+        for (int r = 0; r < n_ranks; ++r) {
+            if (r == rank) { table[k][r] = ch.cols; continue; }
+            if (locals[r] == 0) { table[k][r] = ch.replica + off; continue; }
+            HIP_TRY(hipMemsetAsync(ch.replica + off, 0, (size_t)locals[r] * ch.wp * 8, c->stream));  // the padding words
+            HIP_TRY(hipMemcpy2DAsync(ch.replica + off, ch.wp * 8, chunk_cols[k] + (u64)firsts[r] * stride_words[k],
+                                     stride_words[k] * 8, ch.w * 8, locals[r], hipMemcpyHostToDevice, c->stream));
+            table[k][r] = ch.replica + off;
+            off += (u64)locals[r] * ch.wp;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<unsigned> f(firsts, firsts + n_ranks);
+    HIP_TRY(hipMalloc(&c->d_peer_first, (size_t)n_ranks * 4));
+    HIP_TRY(copy_sync(c, c->d_peer_first, f.data(), (size_t)n_ranks * 4, hipMemcpyHostToDevice));
+    for (size_t k = 0; k < c->chunks.size(); ++k) {
+        HIP_TRY(hipMalloc(&c->chunks[k].d_peer_cols, (size_t)n_ranks * sizeof(u64 *)));
+        HIP_TRY(copy_sync(c, c->chunks[k].d_peer_cols, table[k].data(), (size_t)n_ranks * sizeof(u64 *), hipMemcpyHostToDevice));
+    }
+    c->replicated = true;
+    c->replica_bytes = others * c->col_words * 8;
+    c->exported = true;  // the peers hold copies: the columns must not change any more
+    c->p2p = true;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    c->prepared = false;
+    return UTM_OK;
+}
+
 // One full post + wait round through the mailboxes, four times.  Collective: every shard calls it.  *ok = this
 // shard received every peer's test record in time.  The caller combines the shards' answers and, if all are 1,
 // switches the fused loop to the mailboxes with utm_p2p_use_mailboxes.

@@ -216,6 +216,17 @@ class DeviceMatrix:
         nat.check(nat.lib().utm_p2p_selftest(self._h, ctypes.byref(ok)))
         return bool(ok.value)
 
+    def p2p_replica_from_host(self, rank, firsts, locals_, chunk_arrays):
+        """chunk_arrays[k]: uint64 array (n_samples, >= ceil(n_var_k / 64)) holding EVERY shard's columns of chunk k in
+        host memory; the other shards' columns are uploaded into a local copy (no hipIpc involved)."""
+        n = len(firsts)
+        f = (ctypes.c_uint32 * n)(*[int(x) for x in firsts])
+        loc = (ctypes.c_uint32 * n)(*[int(x) for x in locals_])
+        ptrs = (ctypes.c_void_p * len(chunk_arrays))(*[a.ctypes.data for a in chunk_arrays])
+        strides = (ctypes.c_uint64 * len(chunk_arrays))(*[a.strides[0] // 8 for a in chunk_arrays])
+        nat.check(nat.lib().utm_p2p_replica_from_host(self._h, int(rank), n, f, loc, ptrs, strides))
+        self.p2p = True
+
     @staticmethod
     def p2p_host_mailbox_bytes(n_ranks):
         n = ctypes.c_uint64()

@@ -228,28 +228,35 @@ def bootstrap(rank, world, make_id=None, timeout=300.0):
 
 
 def enable_p2p(shard, transport):
-    """Map every shard's columns into every other shard (hipIpc).  Collective; returns True when all succeed."""
+    """Give every shard access to every other shard's columns and a device-side record exchange.  Collective.
+    In order of preference: hipIpc mappings of the columns (+ a one-time local copy when HBM allows) with mailboxes
+    in uncached device memory; mailboxes in host shared memory instead; and, where device memory cannot be shared
+    between processes at all, a local copy of the peers' columns filled through a host shared-memory file.
+    Returns True when winner columns need no broadcast any more; shard.fused tells whether run() became collective."""
+    import os
     if transport.world == 1:
         return False
-    try:
-        blob = shard.p2p_export()
-    except Exception:  # noqa: BLE001 - any failure means "no P2P here"
-        blob = None
-    size = max(transport.allgather((0.0, -1 if blob is None else len(blob), 0)), key=lambda r: r[1])[1]
-    blobs = transport.allgather_bytes(blob if blob is not None else bytes(max(size, 1)))
-    ok = blob is not None
-    if ok:
+    mapped = False
+    if os.environ.get("UTM_NO_IPC", "0") == "0":
         try:
-            shard.p2p_import(transport.rank, blobs)
-        except Exception:  # noqa: BLE001
-            ok = False
-    everyone = all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0)))
-    if not everyone:
-        shard.p2p = False   # (a context that imported keeps its mappings but columns are broadcast again)
-        return False
-    # the mappings exist everywhere: can the shards also exchange their records on the device?
-    import os
-    boxes = shard.p2p_selftest() if os.environ.get("UTM_MBOX", "device") != "host" else False
+            blob = shard.p2p_export()
+        except Exception:  # noqa: BLE001 - any failure means "no hipIpc here"
+            blob = None
+        size = max(transport.allgather((0.0, -1 if blob is None else len(blob), 0)), key=lambda r: r[1])[1]
+        blobs = transport.allgather_bytes(blob if blob is not None else bytes(max(size, 1)))
+        ok = blob is not None
+        if ok:
+            try:
+                shard.p2p_import(transport.rank, blobs)
+            except Exception:  # noqa: BLE001
+                ok = False
+        mapped = all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0)))
+    if not mapped:
+        shard.p2p = False   # (a context that imported keeps its mappings but they are not used)
+        if not _replicate_via_host(shard, transport):
+            return False
+    # every shard can resolve every winner's column: can the shards also exchange their records on the device?
+    boxes = shard.p2p_selftest() if mapped and os.environ.get("UTM_MBOX", "device") != "host" else False
     if all(r[1] == 1 for r in transport.allgather((0.0, 1 if boxes else 0, 0))):
         shard.p2p_use_mailboxes(True)   # shard.fused: run() is now collective, nothing goes through the host
     elif _host_mailboxes(shard, transport):
@@ -257,38 +264,86 @@ def enable_p2p(shard, transport):
     return True
 
 
-def _host_mailboxes(shard, transport):
-    """Fallback for the record exchange: mailboxes in a POSIX shared-memory file mapped by every shard's process and
-    page-locked for its GPU.  Collective; True when every shard passed the self-test through them."""
+def _shared_file(transport, size):
+    """A zero-filled shared-memory file of `size` bytes that every rank has mapped.  Collective; -> mmap or None.
+    (Unlinked as soon as everybody has it open: the mappings keep it alive.)"""
     import mmap
     import os
-    size = shard.p2p_host_mailbox_bytes(transport.world)
     size = (size + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE
     name = b""
     if transport.rank == 0:
-        path = f"/dev/shm/utmos_amd_mbox_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little')}"
+        path = f"/dev/shm/utmos_amd_{os.getpid()}_{int.from_bytes(os.urandom(4), 'little')}"
         try:
-            with open(path, "wb") as fh:
-                fh.truncate(size)        # zero-filled
-            name = path.encode()
+            room = os.statvfs("/dev/shm")
+            if room.f_bavail * room.f_frsize > size + (1 << 30):
+                with open(path, "wb") as fh:
+                    fh.truncate(size)
+                name = path.encode()
         except OSError:
             name = b""
     name = transport.allgather_bytes(name.ljust(96, b"\0"))[0].rstrip(b"\0").decode()
-    ok = bool(name)
-    if ok:
+    shared = None
+    if name:
         try:
             with open(name, "r+b") as fh:
                 shared = mmap.mmap(fh.fileno(), size)
+        except (OSError, ValueError):
+            shared = None
+    everyone = all(r[1] == 1 for r in transport.allgather((0.0, 1 if shared is not None else 0, 0)))
+    if transport.rank == 0 and name:
+        try:
+            os.unlink(name)
+        except OSError:
+            pass
+    return shared if everyone else None
+
+
+def _replicate_via_host(shard, transport):
+    """No hipIpc: every shard writes its columns into a host shared-memory file and uploads the others' from there
+    into a local copy (one-time cost ~ the matrix over PCIe; needs the matrix to fit into /dev/shm and a second time
+    into every GPU).  Collective; True when every shard holds its copy."""
+    import numpy as np
+    ranges = transport.allgather((0.0, shard.first_sample, shard.n_local))
+    firsts, locals_ = [r[1] for r in ranges], [r[2] for r in ranges]
+    words = [(int(v) + 63) // 64 for v in shard.chunk_vars]
+    offsets = np.concatenate([[0], np.cumsum([w * 8 * shard.n_samples for w in words])]).astype(np.int64)
+    shared = _shared_file(transport, int(offsets[-1]))
+    if shared is None:
+        return False
+    views = [np.frombuffer(shared, dtype=np.uint64, count=shard.n_samples * w, offset=int(off)).reshape(shard.n_samples, w)
+             for w, off in zip(words, offsets)]
+    ok = True
+    try:
+        for k in range(len(views)):
+            views[k][shard.first_sample:shard.first_sample + shard.n_local] = shard.download_columns(k)
+    except Exception:  # noqa: BLE001
+        ok = False
+    ok = all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0)))      # also: everybody's columns are in
+    if ok:
+        try:
+            shard.p2p_replica_from_host(transport.rank, firsts, locals_, views)
+        except Exception:  # noqa: BLE001 - e.g. no room for the copy
+            ok = False
+    ok = all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0)))      # also: nobody reads the file any more
+    del views
+    try:
+        shared.close()
+    except BufferError:
+        pass
+    return ok
+
+
+def _host_mailboxes(shard, transport):
+    """Fallback for the record exchange: mailboxes in a POSIX shared-memory file mapped by every shard's process and
+    page-locked for its GPU.  Collective; True when every shard passed the self-test through them."""
+    shared = _shared_file(transport, shard.p2p_host_mailbox_bytes(transport.world))
+    ok = shared is not None
+    if ok:
+        try:
             shard.p2p_host_mailboxes(shared)
         except Exception:  # noqa: BLE001 - any failure means "not here"
             ok = False
-    everyone = all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0)))   # also: everybody has it open
-    if transport.rank == 0 and name:
-        try:
-            os.unlink(name)              # the mappings keep it alive
-        except OSError:
-            pass
-    if not everyone:
+    if not all(r[1] == 1 for r in transport.allgather((0.0, 1 if ok else 0, 0))):
         return False
     boxes = shard.p2p_selftest()
     return all(r[1] == 1 for r in transport.allgather((0.0, 1 if boxes else 0, 0)))
