@@ -149,10 +149,11 @@ def _cli_rank(rank, world, port, argv, q, extra_env=None):
 
 
 @pytest.mark.parametrize("name", ["select_multi", "select_af", "select_weights_subset", "select_first:store",
-                                  "select_multi:no-p2p-no-rccl", "select_af:no-p2p-no-rccl"])
+                                  "select_multi:no-p2p-no-rccl", "select_af:no-p2p-no-rccl", "select_af:no-ipc"])
 def test_cli_two_processes_sharded_over_samples(name, tmp_path):
     """`utmos select` as one process per shard (here both on the box's single GPU; socket start-up, then the
     device-side exchange): rank 0 writes the golden TSV.  `:store` = the shards load a packed .utm store.
+    `:no-ipc` = no hipIpc: the fused loop on host-filled column copies and host mailboxes.
     `:no-p2p-no-rccl` = mappings switched off and RCCL asked for, which refuses two ranks on one device: the
     shards must agree on the host-staged exchange and still write the golden rows."""
     import multiprocessing as mp
@@ -160,6 +161,8 @@ def test_cli_two_processes_sharded_over_samples(name, tmp_path):
     name, _, variant = name.partition(":")
     from_store = variant == "store"
     extra_env = {"UTMOS_TRANSPORT": "rccl", "UTMOS_P2P": "0"} if variant == "no-p2p-no-rccl" else None
+    if variant == "no-ipc":          # peers' columns through a host shared-memory file, records through host mailboxes
+        extra_env = {"UTM_NO_IPC": "1"}
     argv, out = cli_args(CASES[name], tmp_path)
     if from_store:
         store = str(tmp_path / "m.utm")
