@@ -637,6 +637,36 @@ def test_full_size_select_all_invariants(dev, decremental):
         assert rows[False] == rows[True]
 
 
+@pytest.mark.parametrize("af_dtype", ["f32", "f64"])
+def test_full_size_af_select_all_invariants(dev, af_dtype):
+    """BASELINE configs[2] in full (10M x 2,504 with AF weighting, select all): the winners' scores never grow
+    (submodular), every sample exactly once, all variants captured, a winner's score is at most half its gain
+    (AF <= 0.5) -- and the brute-force loop, the decremental loop and the estimate-score mode give the same rows."""
+    n_var, n_samp = 10_000_000, 2504
+    _, af = dev.synth_host(0, n_var, n_samp, want_cols=False)
+    af = af if af_dtype == "f32" else af.astype(np.float64) / 3.0
+    runs = {}
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.synth_fill(c, seed=0)
+        m.set_af(c, af)
+        for mode in ("brute", "decremental", "estimate"):
+            m.set_decremental(mode != "brute")
+            m.set_af_exact_scores(mode != "estimate")
+            m.reset()
+            idx, new, score = m.run(n_samp)
+            assert len(idx) == n_samp and sorted(idx.tolist()) == list(range(n_samp))
+            assert int(new.sum()) == n_var
+            assert (score <= 0.5 * new + 1e-9).all() and (score > 0).all()
+            if mode != "estimate":
+                assert (np.diff(score) <= 0).all()           # exact float64 scores: non-increasing, ties allowed
+            else:
+                assert np.allclose(score, runs["brute"][2], rtol=1e-6, atol=0)
+            runs[mode] = (idx.tolist(), new.tolist(), score)
+    assert runs["brute"][:2] == runs["decremental"][:2] == runs["estimate"][:2]
+    assert (runs["brute"][2] == runs["decremental"][2]).all()   # the float64 scores too, bit for bit
+
+
 def test_randomised_configurations_against_the_oracle(dev, monkeypatch):
     """Seeded sweep over shapes, chunkings, sample states, weights, AF modes and the decremental switch:
     every configuration must give the oracle's indices, counts and float64 scores."""
