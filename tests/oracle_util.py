@@ -142,3 +142,51 @@ def random_dense(rng, n_var, n_samp, density=0.05, sfs=True):
     forced = rng.integers(0, n_samp, size=n_var)
     m[np.arange(n_var), forced] = True
     return m
+
+
+# ----------------------------------------------------------------- reference-generated traces
+TRACES = os.path.join(GOLD, "traces")
+
+
+def trace_names():
+    return sorted(f[:-5] for f in os.listdir(TRACES) if f.endswith(".json") and f != "count_table.json")
+
+
+def load_trace(name):
+    """A record written by tools/make_traces.py: outputs of the REFERENCE's own code (data only)."""
+    t = json.load(open(os.path.join(TRACES, name + ".json")))
+    if "inputs" in t:
+        t["part_list"] = [load_part(n) for n in t["inputs"]]
+    else:
+        t["part_list"] = []
+        for p in t["parts"]:
+            n_samp = len(p["samples"])
+            gt = np.frombuffer(bytes.fromhex(p["gt_hex"]), dtype=np.uint8).reshape(p["n_rows"], (n_samp + 7) // 8)
+            t["part_list"].append({"GT": gt, "AF": np.array([float.fromhex(x) for x in p["af_hex"]]),
+                                   "samples": np.array(p["samples"])})
+    return t
+
+
+def trace_options(t, tmp_dir=None):
+    """Oracle keyword arguments of a trace (its argv for CLI traces, its recorded call otherwise)."""
+    if t["kind"] == "direct":
+        return {"count": t["count"], "af": bool(t["af"]), "af_dtype": t.get("af_dtype") or "f64"}
+    kw, argv, i = {}, t["argv"], 0
+    while i < len(argv):
+        a = argv[i]
+        if a == "-c":
+            kw["count"] = float(argv[i + 1]); i += 2
+        elif a == "--af":
+            kw["af"] = True; i += 1
+        elif a == "--exclude":
+            kw["exclude"] = argv[i + 1].split(","); i += 2
+        elif a == "--subset":
+            v = argv[i + 1]
+            kw["subset"] = read_list(os.path.join(GOLD, v)) if v.endswith(".txt") else v.split(","); i += 2
+        elif a == "--weights":
+            v = argv[i + 1]
+            kw["weights"] = read_weights(os.path.join(GOLD, v)) if v.endswith(".txt") else {k: w for k, w in t["weights"]}
+            i += 2
+        else:
+            raise ValueError(a)
+    return kw
