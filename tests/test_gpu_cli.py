@@ -230,10 +230,9 @@ def test_cli_input_without_any_carrier_writes_only_the_header(tmp_path):
 @pytest.mark.parametrize("extra", [[], ["--af"], ["--brute-force"]])
 def test_cli_select_all_until_every_variant_is_captured(extra, tmp_path):
     """`-c -1` over the three fixture chunks: about a thousand iterations until tot_captured == N (the reference
-    stops there, select.py:110-112) -- long enough for the CLI's default decremental iterations to take over."""
-    from oracle_util import npo
-    parts = [ou.load_part(n) for n in ("chunk0", "chunk1", "chunk2")]
-    expected = npo.select_tsv(parts, count=-1, af="--af" in extra)
+    stops there, select.py:110-112) -- long enough for the CLI's default decremental iterations to take over.
+    Expected text = what the reference itself wrote for this command (tests/golden/traces, tools/make_traces.py)."""
+    expected = ou.load_trace("all_af64" if "--af" in extra else "all_int")["tsv"]
     out = str(tmp_path / "all.txt")
     run_cli(["-c", "-1", "-o", out] + extra + [os.path.join(ou.GOLD, n + ".npz") for n in ("chunk0", "chunk1", "chunk2")])
     got = open(out).read()
