@@ -9,10 +9,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GRID = {
-    "UTM_TILE_STEPS": ["32", "8"],
-    "UTM_TARGET_WGS": ["2560", "4096", "8192", "16384", "32768"],
-    "UTM_NT_LOADS": ["1", "0"],
+    "UTM_TILE_STEPS": ["0", "8", "4", "2"],
+    "UTM_TARGET_WGS": ["8192", "16384", "32768", "65536"],
+    "UTM_MIN_WGS": ["1024"],
 }
+if os.environ.get("TUNE_GRID"):      # e.g. TUNE_GRID='{"UTM_MIN_WGS": ["256", "4096"]}'
+    GRID = json.loads(os.environ["TUNE_GRID"])
 
 
 def main():

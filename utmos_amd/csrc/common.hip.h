@@ -92,6 +92,7 @@ struct PickArgs {
     u64 *cnt_mirror; // full mode: copy every count here (the persistent copy decremental iterations update), else nullptr
     i64 *afsum_mirror;
     int zero_after;  // full mode: clear the accumulators for the next iteration's atomics
+    int cnt_by_pos;  // cnt[] is indexed by position in act[] (integer full passes), else by local sample
     unsigned *list_n;  // decremental mode: per-chunk newly-covered word counts (read for the accounting, then cleared)
     int n_chunks;
     double *fscore;  // sequential AF scores, or nullptr

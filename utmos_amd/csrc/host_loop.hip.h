@@ -33,17 +33,31 @@ struct LaunchTimer {
 #define UTM_TIMED_LAUNCH(timer, kernel, grid, block, ...) \
     hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, (timer).start, (timer).stop, 0, __VA_ARGS__)
 
+// How one integer scoring launch is to run: counts by position in act[] or by sample; the iteration's pick inside
+// the launch (its last workgroup) or left to a k_pick launch.
+struct IntLaunch {
+    bool by_pos = true;
+    bool fused = false;
+};
+
 template <int STEPS>
 static void launch_score_int(utm_ctx *c, const LaunchTimer &t, const Chunk &ch, unsigned blocks, unsigned group, unsigned n_groups,
-                             bool nt)
+                             bool nt, const IntLaunch &how)
 {
     const u64 *cols = ch.cols;
-    if (nt)
-        UTM_TIMED_LAUNCH(t, (k_score_int<STEPS, true>), dim3(blocks), dim3(256), cols, ch.covered, ch.wp, pending_of(c, ch, true),
-                         (const IterState *)c->d_st, (const unsigned *)c->d_act, c->d_cnt, group, n_groups);
-    else
-        UTM_TIMED_LAUNCH(t, (k_score_int<STEPS, false>), dim3(blocks), dim3(256), cols, ch.covered, ch.wp, pending_of(c, ch, true),
-                         (const IterState *)c->d_st, (const unsigned *)c->d_act, c->d_cnt, group, n_groups);
+    const PickArgs pa = pick_args(c);
+#define UTM_LAUNCH_INT(NT, FUSED)                                                                                                  \
+    UTM_TIMED_LAUNCH(t, (k_score_int<STEPS, NT, FUSED>), dim3(blocks + (FUSED ? 1u : 0u)), dim3(256), cols, ch.covered, ch.wp,       \
+                     pending_of(c, ch, true), (const IterState *)c->d_st, (const unsigned *)c->d_act, c->d_cnt, group, n_groups,   \
+                     how.by_pos ? 1u : 0u, pa)
+    if (how.fused) {
+        if (nt) UTM_LAUNCH_INT(true, true);
+        else UTM_LAUNCH_INT(false, true);
+    } else {
+        if (nt) UTM_LAUNCH_INT(true, false);
+        else UTM_LAUNCH_INT(false, false);
+    }
+#undef UTM_LAUNCH_INT
 }
 
 static void launch_apply_pending(utm_ctx *c)
@@ -86,10 +100,10 @@ static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
 // The streaming kernels (k_score_int, k_score_afs): grid = variant tiles x groups of samples.  Tile = the largest
 // of {32 (AF: 16), 8, 2} KiB that still yields >= UTM_MIN_WGS workgroups; group size such that the grid has about
 // UTM_TARGET_WGS workgroups (>> 256 CUs, small enough units for an even tail), at least one sample per wave.
-static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta = false)
+static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta = false, const IntLaunch &how = IntLaunch())
 {
     static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
-    static const int min_wgs = tune_env("UTM_MIN_WGS", 1024);
+    static const int min_wgs = tune_env("UTM_MIN_WGS", 128);  // (1024 before the pick moved into the launch: 8 KiB tiles now win down to the last iterations)
     static const int min_wgs_big = tune_env("UTM_MIN_WGS_BIG", 8192);  // the 32 KiB tile wants a deeper grid (chr22-sized: +17 % with 8 KiB)
     static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
     static const int nt_env = tune_env("UTM_NT_LOADS", -1);
@@ -107,7 +121,7 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
         const u64 tiles = (steps_total + cand - 1) / cand;
         if (tiles * waves_needed >= (u64)(cand > 8 ? min_wgs_big : min_wgs)) { steps = cand; break; }
     }
-    if (!af && (force_steps == 32 || force_steps == 16 || force_steps == 8 || force_steps == 2)) steps = force_steps;
+    if (!af && (force_steps == 32 || force_steps == 16 || force_steps == 8 || force_steps == 4 || force_steps == 2)) steps = force_steps;
     const u64 tiles = (steps_total + steps - 1) / steps;
     u64 group = ((u64)a_ub * tiles + target_wgs - 1) / target_wgs;
     group = std::max<u64>(4, (group + 3) / 4 * 4);
@@ -125,15 +139,21 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
         else if (steps == 8) UTM_LAUNCH_AFS(8, 16);
         else UTM_LAUNCH_AFS(2, 16);
 #undef UTM_LAUNCH_AFS
-    } else if (steps == 32) launch_score_int<32>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
-    else if (steps == 16) launch_score_int<16>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
-    else if (steps == 8) launch_score_int<8>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
-    else launch_score_int<2>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt);
+    } else if (steps == 32) launch_score_int<32>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
+    else if (steps == 16) launch_score_int<16>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
+    else if (steps == 8) launch_score_int<8>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
+    else if (steps == 4) launch_score_int<4>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
+    else launch_score_int<2>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
 }
 
 // Enqueue the scoring of one iteration for every chunk (and the pending covered update).
-static int enqueue_score(utm_ctx *c, bool force_sequential = false)
+// `fuse_pick`: the caller wants the iteration's pick too and nothing else in between (utm_run on the only shard,
+// integer scores): it then rides in the last chunk's scoring launch and *fused is set; `by_sample` keeps the counts
+// indexed by sample for callers that read them back per sample (utm_peek_scores).
+static int enqueue_score(utm_ctx *c, bool force_sequential = false, bool fuse_pick = false, bool *fused = nullptr,
+                         bool by_sample = false)
 {
+    if (fused) *fused = false;
     const unsigned a_ub = std::max(1u, c->active_ub);
     if (c->af_mode != UTM_AF_NONE && (!c->af_fixed || force_sequential)) {
         launch_score_sequential(c, a_ub);
@@ -163,7 +183,14 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false)
         }
     } else {
         if (c->p2p && !c->replicated) launch_apply_pending(c);  // remote column: read it once, not once per workgroup
-        for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub);
+        static const int fuse_env = tune_env("UTM_FUSE_PICK", 1);
+        IntLaunch how;
+        how.by_pos = !by_sample;
+        for (size_t k = 0; k < c->chunks.size(); ++k) {
+            how.fused = fuse_pick && fuse_env && !by_sample && k + 1 == c->chunks.size();
+            launch_score_streaming(c, c->chunks[k], a_ub, false, how);
+            if (how.fused && fused) *fused = true;
+        }
     }
     HIP_TRY(hipGetLastError());
     return UTM_OK;
@@ -282,6 +309,7 @@ static int sync_state(utm_ctx *c)
     c->iter = c->h_st->iter;
     c->captured_seen = c->h_st->tot;
     c->xseq_host = c->h_st->xseq;
+    if (c->h_st->xerror == 2) return fail(UTM_EHIP, "a scoring launch's partial counts did not all arrive at its pick (internal error)");
     if (c->h_st->xerror) return fail(UTM_ECOMM, "a shard's record did not arrive through the mailboxes in time");
     if (c->h_st->all_exact) c->af_all_exact = true;
     c->active_ub = c->h_st->n_active;
@@ -331,9 +359,10 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
                           (double)c->last_new <= (c->decr_threshold > 0 ? c->decr_threshold : c->decr_interleaved ? 1.0 : 0.2) *
                                                      (double)c->col_words;
         for (i64 j = 0; j < n; ++j) {
+            bool picked = false;
             if (decr) TRY(enqueue_score_decr(c));
-            else TRY(enqueue_score(c));
-            TRY(enqueue_pick_and_exchange(c, decr));
+            else TRY(enqueue_score(c, false, /*fuse_pick=*/c->n_ranks == 1 && !c->comm, &picked));
+            if (!picked) TRY(enqueue_pick_and_exchange(c, decr));
             if (c->n_ranks == 1 && c->active_ub > 0) c->active_ub -= 1;  // exact while the loop is alive
         }
         enq += n;
@@ -403,7 +432,7 @@ extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
     TRY(ensure_prepared(c));
     // with AF every sample's exact reference score is wanted, so all of them take the sequential chain
     c->keep_valid = false;  // the pending winner gets applied here: the next iteration must re-score in full
-    TRY(enqueue_score(c, /*force_sequential=*/true));
+    TRY(enqueue_score(c, /*force_sequential=*/true, false, nullptr, /*by_sample=*/true));
     i64 *d_counts = nullptr;
     double *d_scores = nullptr;
     HIP_TRY(hipMalloc(&d_counts, (size_t)c->n_local * 8));

@@ -163,6 +163,7 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
         a.cnt_mirror = nullptr;
         a.afsum_mirror = nullptr;
         a.zero_after = 0;
+        a.cnt_by_pos = 0;
     } else {
         a.cnt = decr ? c->d_cnt_keep : c->d_cnt;
         a.afsum = nullptr;
@@ -170,6 +171,8 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
         a.cnt_mirror = (!decr && c->decr_enabled) ? c->d_cnt_keep : nullptr;
         a.afsum_mirror = nullptr;
         a.zero_after = decr ? 0 : 1;
+        // integer full passes count by position in act[] (k_score_int's by_pos); the persistent copy is by sample
+        a.cnt_by_pos = (!decr && c->af_mode == UTM_AF_NONE) ? 1 : 0;
     }
     a.list_n = decr ? c->d_listn : nullptr;  // read for the accounting, then cleared, by k_pick
     a.n_chunks = (int)c->chunks.size();

@@ -98,6 +98,99 @@ __device__ __forceinline__ void decide_single(const PickArgs &a, const Cand &bes
     if (p.tot + best.cnt >= a.n_var_total) st->done = 1;
 }
 
+// The pick of an integer-score iteration on the only shard, run INSIDE the scoring launch by its extra last block
+// (k_score_int<.., FUSED>): same arithmetic and decision as k_pick<0>.  The count words (indexed by position in
+// act[]) are being written by the scoring workgroups' agent-scope atomics while this runs; each partial carries
+// 2^40 on top of its count, so a word is final once its upper bits equal the number of variant tiles.  Words are
+// read with returning agent-scope atomics (add 0) -- the coherent read of a word other CUs update atomically --
+// E of them in flight per thread, re-read until complete, then cleared for the next iteration.  act[], weights and
+// the loop state are static during the launch and are loaded before the wait.  The wait is bounded: a launch whose
+// partials never arrive (a logic error, not a data condition) ends the loop with st->xerror = 2.
+#define UTM_FUSED_E 4
+#define UTM_FUSED_SPINS (1u << 22)
+__device__ __forceinline__ void fused_pick(const PickArgs &a, unsigned n_tiles, Cand *fbest /* LDS, 4 entries + flag */)
+{
+    IterState *st = a.st;
+    const unsigned n_active = st->n_active;
+    Preloaded pre{0, 0, 0, 0};
+    if (threadIdx.x == 0) {
+        pre.iter = st->iter;
+        pre.tot = st->tot;
+        pre.n_active_total = st->n_active_total;
+        pre.last_act = n_active ? a.act[n_active - 1] : 0;
+    }
+    const u64 count_mask = (1ull << 40) - 1;
+    Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+    int failed = 0;
+    for (unsigned base = 0; base < n_active && !failed; base += 256 * UTM_FUSED_E) {
+        unsigned s[UTM_FUSED_E];
+        u64 v[UTM_FUSED_E];
+        unsigned need = 0;
+#pragma unroll
+        for (int e = 0; e < UTM_FUSED_E; ++e) {
+            const unsigned i = base + e * 256 + threadIdx.x;
+            s[e] = 0;
+            v[e] = 0;
+            if (i < n_active) {
+                need |= 1u << e;
+                s[e] = a.act[i];
+            }
+        }
+        const unsigned mine = need;
+        for (unsigned spin = 0; need; ++spin) {
+#pragma unroll
+            for (int e = 0; e < UTM_FUSED_E; ++e)
+                if (need >> e & 1)
+                    v[e] = __hip_atomic_fetch_add(&a.cnt[base + e * 256 + threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int e = 0; e < UTM_FUSED_E; ++e)
+                if ((need >> e & 1) && (v[e] >> 40) == n_tiles) need &= ~(1u << e);
+            if (need) {
+                if (spin > UTM_FUSED_SPINS) { failed = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < UTM_FUSED_E; ++e) {
+            if (!(mine >> e & 1)) continue;
+            const unsigned i = base + e * 256 + threadIdx.x;
+            __hip_atomic_store(&a.cnt[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            const u64 c = v[e] & count_mask;
+            if (a.cnt_mirror) a.cnt_mirror[s[e]] = c;
+            double val = (double)c;
+            if (a.weights) val *= a.weights[a.first + s[e]];
+            const Cand cand{val, (i64)a.first + s[e], (i64)c, i};
+            if (better(cand, best)) best = cand;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const Cand other = shfl_cand(best, o);
+        if (better(other, best)) best = other;
+    }
+    int *any_failed = reinterpret_cast<int *>(fbest + 4);
+    if (threadIdx.x == 0) *any_failed = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) fbest[threadIdx.x >> 6] = best;
+    if (failed) *any_failed = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (*any_failed) {
+            st->xerror = 2;
+            st->done = 1;
+            return;
+        }
+        for (int w4 = 1; w4 < 4; ++w4)
+            if (better(fbest[w4], best)) best = fbest[w4];
+        Rec *rc = rec_of(a, a.rank);
+        rc->score = n_active ? best.val : 0.0;
+        rc->idx = n_active ? best.gidx : -1;
+        rc->new_count = n_active ? best.cnt : 0;
+        st->best_pos = best.pos;
+        decide_single(a, best, n_active, pre);
+    }
+}
+
 // Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
 // landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
 #define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
@@ -153,8 +246,9 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
     }
     for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
         const unsigned s = a.act[i];
-        const u64 c = a.cnt[s];
-        if (a.zero_after) a.cnt[s] = 0;  // ready for the next iteration's atomics
+        const unsigned ci = a.cnt_by_pos ? i : s;
+        const u64 c = a.cnt[ci];
+        if (a.zero_after) a.cnt[ci] = 0;  // ready for the next iteration's atomics
         if (a.cnt_mirror) a.cnt_mirror[s] = c;
         double v = (double)c;
         if (a.afsum) {

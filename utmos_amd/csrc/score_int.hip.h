@@ -1,6 +1,7 @@
 // K1, integer scores: the bandwidth-bound bitset reduction (and the XCD-aware block -> tile map).
 #pragma once
 #include "common.hip.h"
+#include "pick.hip.h"
 
 // XCD-aware block -> (tile, group) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
 // b + 8 share one; each XCD has its own L2).  The (tile, group) units are numbered tile-major and cut into
@@ -28,51 +29,79 @@ __device__ __forceinline__ bool tile_of_block(u64 wp, unsigned tile_words, unsig
 // + one ds_read_b128 + 4x(v_and, v_bcnt) per step, a wave reduction and ONE 64-bit atomic per
 // (sample, tile).  Integer adds: exact and order independent.
 // ------------------------------------------------------------------------------------------------
-template <int STEPS, bool NT>
+// FUSED: the pick of the iteration (mask / weight / argmax / decide, pick.hip.h) runs inside the scoring launch,
+// in one extra workgroup (the grid's last block) -- no k_pick launch, no kernel boundary between scoring and pick.
+// Nobody signals and nobody waits on the scoring side: every (sample, tile) partial is added to the sample's
+// count word as `count + 2^40`, so bits 40.. of a count word say how many tile partials it holds, and the picker
+// simply reads the words (returning agent-scope atomics) until each shows all of the launch's tiles
+// (fused_pick).  The scoring workgroups end with their fire-and-forget atomic, as in the plain form.
+#define UTM_ARRIVAL_SHIFT 40
+template <int STEPS, bool NT, bool FUSED>
 __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
-                                                   u64 *__restrict__ cnt, unsigned group_size, unsigned n_groups)
+                                                   u64 *__restrict__ cnt, unsigned group_size, unsigned n_groups,
+                                                   unsigned by_pos, const PickArgs pa)
 {
     __shared__ v4u live[STEPS * 64];  // ~covered of this tile, STEPS KiB
-    if (st->done) return;
+    if (st->done) return;             // (uniform over the launch: only a launch's last workgroup ever sets it)
     unsigned tile, grp;
+    if (FUSED && blockIdx.x == gridDim.x - 1) {  // the picker: one block behind the scoring grid
+        const unsigned n_tiles = (unsigned)((wp + STEPS * UTM_STEP_WORDS - 1) / (STEPS * UTM_STEP_WORDS));
+        fused_pick(pa, n_tiles, reinterpret_cast<Cand *>(&live[0]));
+        return;
+    }
     if (!tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp)) return;
     const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
-
-    v4u *cv = reinterpret_cast<v4u *>(covered + w0);
-    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
-    const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
-    for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
-        v4u c = cv[i];
-        if (wc) {
-            c |= wc[i];
-            // every group of this tile computes the same words; group 0 stores them.  A racing reader
-            // sees old or new words and ORs the winner in itself, so either is right.
-            if (grp == 0) cv[i] = c;
-        }
-        live[i] = ~c;
-    }
-    __syncthreads();
+    const bool full = nsteps == STEPS;
 
     const unsigned n_active = st->n_active;
     const unsigned lo = grp * group_size;
     const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int U = STEPS < 8 ? STEPS : 8;  // loads in flight per wave: U KiB
-    for (unsigned i = lo + wave; i < hi; i += 4) {
-        const unsigned s = act[i];
-        const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
+#define UTM_COL_LOAD(ptr) (NT ? __builtin_nontemporal_load(ptr) : *(ptr))
+
+    // Software pipeline: the first U KiB of this wave's first sample are requested BEFORE the tile is staged (the
+    // two do not depend on each other: a short-lived workgroup would otherwise spend half its life waiting for
+    // the tile, then again for its columns), and a sample's successor (index from act[], then its first U KiB) is
+    // requested before the sample's reduction and atomic.
+    unsigned i = lo + wave;
+    unsigned s = i < hi ? act[i] : 0;
+    unsigned s_next = i + 4 < hi ? act[i + 4] : 0;
+    const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
+    v4u x[U];
+    if (i < hi && full) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = UTM_COL_LOAD(p + u * 64);
+    }
+
+    v4u *cv = reinterpret_cast<v4u *>(covered + w0);
+    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
+    const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
+    for (int k = threadIdx.x; k < nsteps * 64; k += 256) {
+        v4u c = cv[k];
+        if (wc) {
+            c |= wc[k];
+            // every group of this tile computes the same words; group 0 stores them.  A racing reader
+            // sees old or new words and ORs the winner in itself, so either is right.
+            if (grp == 0) cv[k] = c;
+        }
+        live[k] = ~c;
+    }
+    __syncthreads();
+
+    while (i < hi) {
         unsigned acc = 0;
-        if (nsteps == STEPS) {
+        if (full) {
 #pragma unroll 1
             for (int j0 = 0; j0 < STEPS; j0 += U) {
-                v4u x[U];
+                if (j0) {
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    x[u] = NT ? __builtin_nontemporal_load(p + (j0 + u) * 64) : p[(j0 + u) * 64];
+                    for (int u = 0; u < U; ++u) x[u] = UTM_COL_LOAD(p + (j0 + u) * 64);
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const v4u b = x[u] & live[(j0 + u) * 64 + lane];
@@ -85,7 +114,25 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
                 acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
             }
         }
+        const unsigned done_i = i, done_s = s;
+        i += 4;
+        s = s_next;
+        if (i < hi) {
+            s_next = i + 4 < hi ? act[i + 4] : 0;
+            p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) x[u] = UTM_COL_LOAD(p + u * 64);
+            }
+        }
         acc = wave_sum_u32(acc);
-        if (lane == 0 && acc) atomicAdd(&cnt[s], (u64)acc);
+        // counts are kept by position in act[] (by_pos) where the pick reads them by position too: one
+        // dependent load less on its critical path.  FUSED: every partial arrives, a zero one too.
+        if (FUSED) {
+            if (lane == 0) atomicAdd(&cnt[done_i], (u64)acc + (1ull << UTM_ARRIVAL_SHIFT));
+        } else if (lane == 0 && acc) {
+            atomicAdd(&cnt[by_pos ? done_i : done_s], (u64)acc);
+        }
     }
+#undef UTM_COL_LOAD
 }
