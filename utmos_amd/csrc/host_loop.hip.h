@@ -187,7 +187,9 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, bool fuse_pi
         IntLaunch how;
         how.by_pos = !by_sample;
         for (size_t k = 0; k < c->chunks.size(); ++k) {
-            how.fused = fuse_pick && fuse_env && !by_sample && k + 1 == c->chunks.size();
+            // (weighted scores are float64 products: they stay with k_pick, the fused pick compares integer counts)
+            // ... and so do the full passes of a decremental run (they mirror their counts by sample)
+            how.fused = fuse_pick && fuse_env && !by_sample && !c->have_weights && !c->decr_enabled && k + 1 == c->chunks.size();
             launch_score_streaming(c, c->chunks[k], a_ub, false, how);
             if (how.fused && fused) *fused = true;
         }

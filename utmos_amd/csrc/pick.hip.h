@@ -98,17 +98,33 @@ __device__ __forceinline__ void decide_single(const PickArgs &a, const Cand &bes
     if (p.tot + best.cnt >= a.n_var_total) st->done = 1;
 }
 
-// The pick of an integer-score iteration on the only shard, run INSIDE the scoring launch by its extra last block
-// (k_score_int<.., FUSED>): same arithmetic and decision as k_pick<0>.  The count words (indexed by position in
+// The pick of an unweighted integer-score iteration on the only shard, run INSIDE the scoring launch by its extra
+// last block (k_score_int<.., FUSED>): same decision as k_pick<0>.  The count words (indexed by position in
 // act[]) are being written by the scoring workgroups' agent-scope atomics while this runs; each partial carries
 // 2^40 on top of its count, so a word is final once its upper bits equal the number of variant tiles.  Words are
 // read with returning agent-scope atomics (add 0) -- the coherent read of a word other CUs update atomically --
-// E of them in flight per thread, re-read until complete, then cleared for the next iteration.  act[], weights and
-// the loop state are static during the launch and are loaded before the wait.  The wait is bounded: a launch whose
-// partials never arrive (a logic error, not a data condition) ends the loop with st->xerror = 2.
-#define UTM_FUSED_E 4
+// E consecutive words per thread in flight, re-read until complete, then cleared for the next iteration.  act[]
+// and the loop state are static during the launch and are loaded before the wait.  Scores are the counts
+// themselves here (no weights: the launcher keeps weighted runs on k_pick), compared as integers: count
+// descending, global index ascending = np.argmax's first maximum.  The wait is bounded: a launch whose partials
+// never arrive (a logic error, not a data condition) ends the loop with st->xerror = 2.
+#ifndef UTM_FUSED_E
+#define UTM_FUSED_E 4  // (5, 8, 10 in flight per thread measured 1-2 % slower at 2,504 samples: more registers, lower occupancy)
+#endif
+#ifndef UTM_FUSED_SLEEP
+#define UTM_FUSED_SLEEP 4
+#endif
+#define UTM_PICK_PAD 4096  // spare entries behind act[] and cnt[] (>= 256 * UTM_FUSED_E)
 #define UTM_FUSED_SPINS (1u << 22)
-__device__ __forceinline__ void fused_pick(const PickArgs &a, unsigned n_tiles, Cand *fbest /* LDS, 4 entries + flag */)
+struct IntCand {
+    u64 cnt;
+    unsigned s, pos;  // local sample, position in act[]
+};
+__device__ __forceinline__ bool better_int(const IntCand &a, const IntCand &b)
+{
+    return a.cnt > b.cnt || (a.cnt == b.cnt && a.s < b.s);
+}
+__device__ __forceinline__ void fused_pick(const PickArgs &a, unsigned n_tiles, IntCand *fbest /* LDS, 4 entries + flag */)
 {
     IterState *st = a.st;
     const unsigned n_active = st->n_active;
@@ -120,53 +136,46 @@ __device__ __forceinline__ void fused_pick(const PickArgs &a, unsigned n_tiles, 
         pre.last_act = n_active ? a.act[n_active - 1] : 0;
     }
     const u64 count_mask = (1ull << 40) - 1;
-    Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+    IntCand best{0, 0xFFFFFFFFu, 0};  // (no selectable sample: stays like this, n_active == 0 decides)
     int failed = 0;
     for (unsigned base = 0; base < n_active && !failed; base += 256 * UTM_FUSED_E) {
+        const unsigned i0 = base + threadIdx.x;  // a wave instruction reads 64 consecutive words (4 lines); E of them in flight
         unsigned s[UTM_FUSED_E];
-        u64 v[UTM_FUSED_E];
         unsigned need = 0;
 #pragma unroll
-        for (int e = 0; e < UTM_FUSED_E; ++e) {
-            const unsigned i = base + e * 256 + threadIdx.x;
-            s[e] = 0;
-            v[e] = 0;
-            if (i < n_active) {
-                need |= 1u << e;
-                s[e] = a.act[i];
-            }
+        for (int e = 0; e < UTM_FUSED_E; ++e) {  // (act[] and cnt[] are allocated with UTM_PICK_PAD spare entries: no bounds branches)
+            s[e] = a.act[i0 + e * 256];
+            if (i0 + e * 256 < n_active) need |= 1u << e;
         }
-        const unsigned mine = need;
+        u64 *words = a.cnt + i0;
         for (unsigned spin = 0; need; ++spin) {
+            // (LLVM lowers the idempotent fetch_add to an agent-scope atomic 64-bit load: global_load_dwordx2 sc1)
+            u64 v[UTM_FUSED_E];
 #pragma unroll
             for (int e = 0; e < UTM_FUSED_E; ++e)
-                if (need >> e & 1)
-                    v[e] = __hip_atomic_fetch_add(&a.cnt[base + e * 256 + threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[e] = __hip_atomic_fetch_add(words + e * 256, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a complete word is consumed at once: nothing but the `need` mask and the running best lives across rounds
 #pragma unroll
-            for (int e = 0; e < UTM_FUSED_E; ++e)
-                if ((need >> e & 1) && (v[e] >> 40) == n_tiles) need &= ~(1u << e);
+            for (int e = 0; e < UTM_FUSED_E; ++e) {
+                const bool fin = (need >> e & 1) && (v[e] >> 40) == n_tiles;
+                if (fin) __hip_atomic_store(words + e * 256, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                const IntCand cand{fin ? (v[e] & count_mask) : 0ull, fin ? s[e] : 0xFFFFFFFFu, i0 + e * 256};
+                if (better_int(cand, best)) best = cand;
+                need &= ~((fin ? 1u : 0u) << e);
+            }
             if (need) {
                 if (spin > UTM_FUSED_SPINS) { failed = 1; break; }
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(UTM_FUSED_SLEEP);
             }
-        }
-#pragma unroll
-        for (int e = 0; e < UTM_FUSED_E; ++e) {
-            if (!(mine >> e & 1)) continue;
-            const unsigned i = base + e * 256 + threadIdx.x;
-            __hip_atomic_store(&a.cnt[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-            const u64 c = v[e] & count_mask;
-            if (a.cnt_mirror) a.cnt_mirror[s[e]] = c;
-            double val = (double)c;
-            if (a.weights) val *= a.weights[a.first + s[e]];
-            const Cand cand{val, (i64)a.first + s[e], (i64)c, i};
-            if (better(cand, best)) best = cand;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const Cand other = shfl_cand(best, o);
-        if (better(other, best)) best = other;
+        IntCand other;
+        other.cnt = __shfl_xor(best.cnt, o, 64);
+        other.s = __shfl_xor(best.s, o, 64);
+        other.pos = __shfl_xor(best.pos, o, 64);
+        if (better_int(other, best)) best = other;
     }
     int *any_failed = reinterpret_cast<int *>(fbest + 4);
     if (threadIdx.x == 0) *any_failed = 0;
@@ -181,13 +190,14 @@ __device__ __forceinline__ void fused_pick(const PickArgs &a, unsigned n_tiles, 
             return;
         }
         for (int w4 = 1; w4 < 4; ++w4)
-            if (better(fbest[w4], best)) best = fbest[w4];
+            if (better_int(fbest[w4], best)) best = fbest[w4];
+        const Cand win{(double)best.cnt, (i64)a.first + best.s, (i64)best.cnt, best.pos};
         Rec *rc = rec_of(a, a.rank);
-        rc->score = n_active ? best.val : 0.0;
-        rc->idx = n_active ? best.gidx : -1;
-        rc->new_count = n_active ? best.cnt : 0;
-        st->best_pos = best.pos;
-        decide_single(a, best, n_active, pre);
+        rc->score = n_active ? win.val : 0.0;
+        rc->idx = n_active ? win.gidx : -1;
+        rc->new_count = n_active ? win.cnt : 0;
+        st->best_pos = win.pos;
+        decide_single(a, win, n_active, pre);
     }
 }
 

@@ -36,8 +36,11 @@ __device__ __forceinline__ bool tile_of_block(u64 wp, unsigned tile_words, unsig
 // simply reads the words (returning agent-scope atomics) until each shows all of the launch's tiles
 // (fused_pick).  The scoring workgroups end with their fire-and-forget atomic, as in the plain form.
 #define UTM_ARRIVAL_SHIFT 40
+#ifndef UTM_SCORE_WAVES
+#define UTM_SCORE_WAVES(STEPS) 1  // (forcing 8 waves/SIMD on the small tiles spilled the picker's registers: slower)
+#endif
 template <int STEPS, bool NT, bool FUSED>
-__global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+__global__ __launch_bounds__(256, UTM_SCORE_WAVES(STEPS)) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, unsigned group_size, unsigned n_groups,
@@ -46,9 +49,11 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
     __shared__ v4u live[STEPS * 64];  // ~covered of this tile, STEPS KiB
     if (st->done) return;             // (uniform over the launch: only a launch's last workgroup ever sets it)
     unsigned tile, grp;
-    if (FUSED && blockIdx.x == gridDim.x - 1) {  // the picker: one block behind the scoring grid
+    // the picker: one block behind the scoring grid (dispatched last: it starts polling when the launch is nearly over;
+    // as the first block it polled all launch long and cost 2 %)
+    if (FUSED && blockIdx.x == gridDim.x - 1) {
         const unsigned n_tiles = (unsigned)((wp + STEPS * UTM_STEP_WORDS - 1) / (STEPS * UTM_STEP_WORDS));
-        fused_pick(pa, n_tiles, reinterpret_cast<Cand *>(&live[0]));
+        fused_pick(pa, n_tiles, reinterpret_cast<IntCand *>(&live[0]));
         return;
     }
     if (!tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp)) return;
@@ -63,6 +68,35 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int U = STEPS < 8 ? STEPS : 8;  // loads in flight per wave: U KiB
 #define UTM_COL_LOAD(ptr) (NT ? __builtin_nontemporal_load(ptr) : *(ptr))
+    // One batch = U KiB of a column.  Full tiles use immediate offsets; the last tile of a column may be shorter
+    // than STEPS KiB: there the missing steps re-read the tile's last KiB and count as zero (wave-uniform clamp and
+    // select), so it is batched too -- on its own code path, which keeps the clamps out of the full tiles' registers.
+    const v4u zero4 = {0, 0, 0, 0};
+#define UTM_BATCH_LOAD(J0)                                                                 \
+    if (full) {                                                                            \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) x[u] = UTM_COL_LOAD(p + ((J0) + u) * 64); \
+    } else {                                                                               \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                      \
+        {                                                                                  \
+            const int step = (J0) + u;                                                     \
+            x[u] = UTM_COL_LOAD(p + (step < nsteps ? step : nsteps - 1) * 64);             \
+        }                                                                                  \
+    }
+#define UTM_BATCH_COUNT(J0)                                                                \
+    if (full) {                                                                            \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                      \
+        {                                                                                  \
+            const v4u b = x[u] & live[((J0) + u) * 64 + lane];                             \
+            acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                  \
+        }                                                                                  \
+    } else {                                                                               \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                      \
+        {                                                                                  \
+            const int step = (J0) + u;                                                     \
+            const v4u b = (step < nsteps ? x[u] : zero4) & live[(step < nsteps ? step : 0) * 64 + lane]; \
+            acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                  \
+        }                                                                                  \
+    }
 
     // Software pipeline: the first U KiB of this wave's first sample are requested BEFORE the tile is staged (the
     // two do not depend on each other: a short-lived workgroup would otherwise spend half its life waiting for
@@ -73,10 +107,7 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
     unsigned s_next = i + 4 < hi ? act[i + 4] : 0;
     const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
     v4u x[U];
-    if (i < hi && full) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = UTM_COL_LOAD(p + u * 64);
-    }
+    if (i < hi) { UTM_BATCH_LOAD(0) }
 
     v4u *cv = reinterpret_cast<v4u *>(covered + w0);
     const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
@@ -95,24 +126,10 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
 
     while (i < hi) {
         unsigned acc = 0;
-        if (full) {
 #pragma unroll 1
-            for (int j0 = 0; j0 < STEPS; j0 += U) {
-                if (j0) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) x[u] = UTM_COL_LOAD(p + (j0 + u) * 64);
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const v4u b = x[u] & live[(j0 + u) * 64 + lane];
-                    acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
-                }
-            }
-        } else {
-            for (int j = 0; j < nsteps; ++j) {
-                const v4u b = p[j * 64] & live[j * 64 + lane];
-                acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
-            }
+        for (int j0 = 0; j0 < nsteps; j0 += U) {
+            if (j0) { UTM_BATCH_LOAD(j0) }
+            UTM_BATCH_COUNT(j0)
         }
         const unsigned done_i = i, done_s = s;
         i += 4;
@@ -120,10 +137,7 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
         if (i < hi) {
             s_next = i + 4 < hi ? act[i + 4] : 0;
             p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
-            if (full) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) x[u] = UTM_COL_LOAD(p + u * 64);
-            }
+            UTM_BATCH_LOAD(0)
         }
         acc = wave_sum_u32(acc);
         // counts are kept by position in act[] (by_pos) where the pick reads them by position too: one
@@ -135,4 +149,6 @@ __global__ __launch_bounds__(256) void k_score_int(const u64 *__restrict__ cols,
         }
     }
 #undef UTM_COL_LOAD
+#undef UTM_BATCH_LOAD
+#undef UTM_BATCH_COUNT
 }

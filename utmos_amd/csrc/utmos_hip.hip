@@ -253,10 +253,12 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     *out = c;  // so that a failing allocation below can still be destroyed by the caller
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&c->d_state, n_samp_local));
-    HIP_TRY(hipMalloc(&c->d_cnt, (size_t)n_samp_local * 8));
+    HIP_TRY(hipMalloc(&c->d_cnt, ((size_t)n_samp_local + UTM_PICK_PAD) * 8));  // (the fused pick reads whole groups of words)
     HIP_TRY(hipMalloc(&c->d_afsum, (size_t)n_samp_local * 8));
     HIP_TRY(hipMalloc(&c->d_fscore, (size_t)n_samp_local * 8));
-    HIP_TRY(hipMalloc(&c->d_act, (size_t)n_samp_local * 4));
+    HIP_TRY(hipMalloc(&c->d_act, ((size_t)n_samp_local + UTM_PICK_PAD) * 4));
+    HIP_TRY(hipMemsetAsync(c->d_act, 0, ((size_t)n_samp_local + UTM_PICK_PAD) * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_cnt, 0, ((size_t)n_samp_local + UTM_PICK_PAD) * 8, c->stream));
     HIP_TRY(hipMalloc(&c->d_varcount, (size_t)n_samp_local * 8));
     HIP_TRY(hipMalloc(&c->d_st, sizeof(IterState)));
     HIP_TRY(hipHostMalloc(&c->h_st, sizeof(IterState)));
