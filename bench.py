@@ -6,12 +6,18 @@ A *step* is one full `select all` run of the greedy loop (utmos/select.py:69-112
 `value` = greedy iterations per second over the K timed steps (all ranks, max time over ranks).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W          # one rank per GPU; samples sharded; RCCL exchange
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W          # one rank per GPU; samples sharded over the ranks
 
-With N > 1 the same 10M x 2,504 problem is sharded over the sample axis (strong scaling): every
-iteration ends with one ncclAllGather of {best record, best column} per rank.  No torch is imported:
-ranks find each other through RANK/LOCAL_RANK/WORLD_SIZE and a rendezvous file for the ncclUniqueId.
+N = 1, default workload: after the headline the other single-GPU BASELINE configurations run one step each (cfg3
+`--af` float32, cfg1 chr22-sized, one rank's share of cfg4 for 20 iterations, cfg5's 156 GB for 10) and are
+attached under `also`, each with its own it/s, bytes and roofline fraction.
+
+N > 1: the same 10M x 2,504 problem is sharded over the sample axis (strong scaling).  The line says how the shards
+met every iteration (`exchange`, `rccl_ranks`, `p2p_replica_bytes`); the headline is the default exchange (device
+mailboxes over hipIpc mappings) and the same steps are timed again with north_star's RCCL protocol (ncclAllGather
+of the records + ncclBroadcast of the winner's column) under `also_exchange`.  No torch is imported: ranks find
+each other through RANK/LOCAL_RANK/WORLD_SIZE and a rendezvous file.
 """
 import argparse
 import json
@@ -22,21 +28,23 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-T_START = time.time()
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-
+METRIC = "greedy iterations/sec + achieved HBM GB/s, 10M variants × 2.5k samples"   # BASELINE.json's string
 
 # BASELINE.json `configs`, by name.  cfg2 is the default (the metric's configuration); cfg4 is meant for --gpus 8
-# (12,500 columns = 78 GB per rank) and cfg5 for one GPU (156 GB in ten chunks); both select a fixed number of
-# samples instead of all of them.
+# (12,500 columns = 78 GB per rank; `cfg4rank` is that one-rank share on one GPU) and cfg5 for one GPU (156 GB in ten
+# chunks); both select a fixed number of samples instead of all of them.
 WORKLOADS = {
     "cfg1": ("1.1M x 2,504 (chr22-sized), select all", dict(n_var=1_103_547, n_samp=2504, select=-1)),
     "cfg2": ("10M x 2,504, select all", dict(n_var=10_000_000, n_samp=2504, select=-1)),
     "cfg3": ("10M x 2,504 with float32 AF weighting, select all", dict(n_var=10_000_000, n_samp=2504, select=-1, af=True)),
     "cfg4": ("50M x 100,000 over the ranks, first 20 iterations", dict(n_var=50_000_000, n_samp=100_000, select=20)),
+    "cfg4rank": ("one rank's share of cfg4 on one GPU: 50M x 12,500, first 20 iterations",
+                 dict(n_var=50_000_000, n_samp=12_500, select=20)),
     "cfg5": ("500M x 2,504 in chunks of 50M, first 10 iterations",
              dict(n_var=500_000_000, n_samp=2504, select=10, chunk_vars=50_000_000)),
 }
+ALSO = ("cfg3", "cfg1", "cfg4rank", "cfg5")       # attached to the default single-GPU line, one step each
 
 
 def parse():
@@ -53,15 +61,19 @@ def parse():
                    help="f32 = the reference's hdf5 values (configs[2]); f64 = its in-memory values")
     p.add_argument("--chunk-vars", type=int, default=0, help="split the variant axis into chunks of this many variants")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-vars", type=int, default=1_000_000)
+    p.add_argument("--cpu-sample-vars", type=int, default=1_000_000, help="rows of the CPU baseline's sample when full N is not timed")
+    p.add_argument("--cpu-budget-s", type=float, default=40.0,
+                   help="CPU seconds the reference port may take; one iteration at full N is timed when it fits here and in host RAM")
     p.add_argument("--no-roofline-pass", action="store_true")
+    p.add_argument("--no-also", action="store_true", help="N = 1: skip the other BASELINE configurations after the headline")
     p.add_argument("--af-estimate-scores", action="store_true",
                    help="AF: do not chain unambiguous winners (same rows; reported scores are estimates)")
     p.add_argument("--decremental", action="store_true",
                    help="SURVEY 8f-4 shortcut (exact, reads far fewer bytes): reported separately, never the default")
     p.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip rank 0's single-GPU re-run and comparison")
-    p.add_argument("--exchange", choices=["auto", "rccl"], default="auto",
-                   help="N > 1: auto = device mailboxes over hipIpc mappings when every rank can, else RCCL; rccl = force RCCL")
+    p.add_argument("--exchange", choices=["auto", "mailboxes", "rccl", "both"], default="both",
+                   help="N > 1: both = headline through the default exchange (mailboxes, else RCCL) and the same steps again "
+                        "through RCCL (also_exchange); auto / mailboxes / rccl = that one only")
     p.add_argument("--decr-threshold", type=float, default=0.0, help="--decremental: newly-covered word fraction below which an iteration goes decremental (0 = library default)")
     p.add_argument("--pmc-traffic", choices=["live", "recorded", "off"], default="live",
                    help="roofline.traffic: live = two rocprofv3 --pmc child runs of one step of this workload (N = 1), "
@@ -69,15 +81,83 @@ def parse():
     p.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
                    help="a BASELINE.json configuration by name (sets the shape flags): " +
                         "; ".join(f"{k}: {v[0]}" for k, v in sorted(WORKLOADS.items())))
-    p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the exchange path)")
+    p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the RCCL exchange)")
     args = p.parse_args()
+    args.explicit_shape = bool(args.workload) or any(a.startswith(("--n-var", "--n-samp", "--select", "--af", "--chunk-vars",
+                                                                   "--decremental", "--seed")) for a in sys.argv[1:])
     if args.workload:
         for key, value in WORKLOADS[args.workload][1].items():
             setattr(args, key, value)
     return args
 
 
-def live_pmc_traffic(args):
+# ------------------------------------------------------------------------------------------------ building blocks
+def spec_of(args):
+    return dict(n_var=args.n_var, n_samp=args.n_samp, select=args.select, af=args.af, af_dtype=args.af_dtype,
+                chunk_vars=args.chunk_vars, seed=args.seed)
+
+
+def build_matrix(device, spec, dev_index, first=0, n_local=None):
+    """The synthetic matrix of `spec`, generated in HBM (DESIGN.md 'Synthetic input').  -> (matrix, seconds)."""
+    import numpy as np
+    n_total = spec["n_samp"]
+    m = device.DeviceMatrix(n_total, device=dev_index, first_sample=first, n_local=n_total if n_local is None else n_local)
+    chunk_vars = spec.get("chunk_vars") or spec["n_var"]
+    t0 = time.perf_counter()
+    v0 = 0
+    while v0 < spec["n_var"]:
+        nv = min(chunk_vars, spec["n_var"] - v0)
+        c = m.add_chunk(nv)
+        m.synth_fill(c, seed=spec.get("seed", 0), first_var_global=v0)
+        if spec.get("af"):
+            _, af = device.synth_host(spec.get("seed", 0), nv, n_total, first_var_global=v0, want_cols=False)
+            # f64: full 53-bit mantissas, like the reference's ac/an quotients
+            m.set_af(c, af if spec.get("af_dtype", "f32") == "f32" else af.astype(np.float64) / 3.0)
+        v0 += nv
+    return m, time.perf_counter() - t0
+
+
+def select_count(spec):
+    return spec["n_samp"] if spec["select"] < 0 else min(spec["select"], spec["n_samp"])
+
+
+def timed_steps(m, k_sel, steps, warmup, sync_max):
+    """W untimed + K timed steps, bracketed by barriers; the maximum time over the ranks.  A step = reset + run."""
+    def one_step():
+        m.reset()
+        return m.run(k_sel)
+    for _ in range(warmup):
+        one_step()
+    sync_max(0.0)                     # barrier (run() returns only after its stream has drained)
+    t0 = time.perf_counter()
+    iters, loop_ms, rows = 0, 0.0, None
+    for _ in range(steps):
+        rows = one_step()
+        iters += len(rows[0])
+        loop_ms += m.stats()["loop_ms"]
+    elapsed = sync_max(time.perf_counter() - t0)
+    return dict(iters=iters, elapsed=elapsed, loop_ms=loop_ms, rows=rows, stats=m.stats())
+
+
+def roofline_pass(m, k_sel, af, rank=0):
+    """The same step once more with every scoring dispatch stamped by its own HIP events (on the context's stream):
+    algorithmic bytes of the step / summed scoring-kernel time."""
+    m.set_profile(True)
+    m.reset()
+    m.run(k_sel)
+    ps = m.stats()
+    m.set_profile(False)
+    if ps["score_ms"] <= 0:
+        return None
+    achieved = ps["algo_bytes"] / (ps["score_ms"] * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel": "k_score_afs (+ k_score_afq for the first launches)" if af else "k_score_int (pick fused in on one GPU)",
+            "launches": ps["score_launches"], "avg_launch_us": ps["score_ms"] * 1e3 / max(1, ps["score_launches"]),
+            "algo_bytes_per_launch": ps["algo_bytes"] / max(1, ps["score_launches"]), "rank": rank}
+
+
+def live_pmc_traffic(spec, extra):
     """HBM bytes per scoring launch from the PMC counters, as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE and
     WRITE_SIZE in separate `rocprofv3 --pmc` passes with nothing else enabled (KiB units; on gfx950 FETCH_SIZE reports
     half of a wide coalesced read -> x2).  Each pass is a child process running ONE step of this same workload.
@@ -92,13 +172,11 @@ def live_pmc_traffic(args):
         return None
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None      # this process is itself being profiled: no nested profiler runs
-    work = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-pass", "--pmc-traffic", "off",
-            "--n-var", str(args.n_var), "--n-samp", str(args.n_samp), "--select", str(args.select), "--seed", str(args.seed),
-            "--chunk-vars", str(args.chunk_vars)]
-    if args.af:
-        work += ["--af", "--af-dtype", args.af_dtype]
-    if args.af_estimate_scores:
-        work += ["--af-estimate-scores"]
+    work = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-pass", "--no-also", "--pmc-traffic", "off",
+            "--n-var", str(spec["n_var"]), "--n-samp", str(spec["n_samp"]), "--select", str(spec["select"]),
+            "--seed", str(spec["seed"]), "--chunk-vars", str(spec["chunk_vars"])] + extra
+    if spec["af"]:
+        work += ["--af", "--af-dtype", spec["af_dtype"]]
     tmp = os.environ.get("TMPDIR", "/tmp")
     per_launch = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -125,20 +203,36 @@ def live_pmc_traffic(args):
                           "read bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950), write bytes = WRITE_SIZE KiB x 1024")
 
 
-def rendezvous_id(rank, world, make_id):
-    from utmos_amd.sharded import rendezvous_unique_id
-    return rendezvous_unique_id(rank, make_id)
+def mem_available_gb():
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
 
 
-def cpu_baseline(args, device_mod):
-    """The reference's algorithm on the host, on a bounded sample of the same synthetic workload:
-    oracle.score_rowloop = the per-row numpy loop of utmos/select.py:33-48, single thread, first 3
-    iterations on the first `cpu_sample_vars` variants; rate scaled to the full variant count
-    (time per iteration is linear in rows).  Second line: the packed C oracle with OpenMP."""
+def cpu_baseline(args, device_mod, gpu_winners):
+    """The reference's algorithm on the host cores (rank 0, N = 1): oracle.score_rowloop = the per-row numpy loop of
+    utmos/select.py:33-48, one thread.  BASELINE.md 4 asks for full N when host RAM allows the unpacked bool matrix; one
+    full-N iteration costs ~95 s, so it is timed only when that fits --cpu-budget-s too -- otherwise the first
+    `cpu_sample_vars` variants of the same matrix: the first 3 iterations (nothing captured yet: the most expensive
+    ones) and one iteration from the state the GPU run had reached after S/2 selections (captured rows are skipped
+    there); rates scaled to the full variant count (time per iteration is linear in rows).
+    Second line: the packed C oracle with OpenMP."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_util as ou
-    n_var = min(args.cpu_sample_vars, args.n_var)
+    ram_gb = mem_available_gb()
+    full_bytes_gb = args.n_var * args.n_samp / 1e9 * 1.25        # bool matrix + the packed columns it is unpacked from
+    full_est_s = args.n_var * 9.5e-6                             # 9-10 us per row measured with the reference itself (BASELINE.md 2)
+    full_n = ram_gb > full_bytes_gb + 8 and full_est_s * 1.3 < args.cpu_budget_s
+    n_var = args.n_var if full_n else min(args.cpu_sample_vars, args.n_var)
+    why = ("full N" if full_n else
+           f"sample: full N needs {full_bytes_gb:.0f} GB of host RAM ({ram_gb:.0f} GB available) and ~{full_est_s:.0f} s per "
+           f"iteration (budget {args.cpu_budget_s:.0f} s)")
     with device_mod.DeviceMatrix(args.n_samp, device=0) as m:
         c = m.add_chunk(n_var)
         m.synth_fill(c, seed=args.seed)
@@ -146,29 +240,58 @@ def cpu_baseline(args, device_mod):
     bits = np.unpackbits(cols.view(np.uint8), axis=1, bitorder="little")[:, :n_var]
     dense = np.ascontiguousarray(bits.T).astype(bool)
     del bits
+    scale = n_var / args.n_var
     state = np.ones(args.n_samp, np.uint8)
-    iters = 3
+    iters = 1 if full_n else 3
     t0 = time.perf_counter()
     for _ in range(iters):
         best, _new = ou.npo.score_rowloop(dense, state)
         state[best] = 0
     dt = time.perf_counter() - t0
-    scale = n_var / args.n_var
     port = {"value": iters / dt * scale, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"first {iters} greedy iterations on the first {n_var} of {args.n_var} synthetic variants x "
-                      f"{args.n_samp} samples (numpy row loop, {dt:.1f} s); rate scaled by {scale:.4g} to the full variant count",
-            "host_cpus": os.cpu_count()}
+            "sample": f"first {iters} greedy iteration(s) on {'all' if full_n else 'the first'} {n_var} of {args.n_var} synthetic "
+                      f"variants x {args.n_samp} samples (numpy row loop, {dt:.1f} s); rate scaled by {scale:.4g} to the full variant count",
+            "rows_timed": n_var, "full_n": bool(full_n), "why": why, "host_cpus": os.cpu_count(), "host_mem_available_gb": round(ram_gb, 1)}
+    if not full_n and gpu_winners is not None and len(gpu_winners) >= 2:
+        half = len(gpu_winners) // 2
+        mid = np.ones(args.n_samp, np.uint8)
+        mid[np.asarray(gpu_winners[:half])] = 0          # the GPU run's first S/2 winners are "used": their variants are covered
+        t0 = time.perf_counter()
+        ou.npo.score_rowloop(dense, mid)
+        dt_mid = time.perf_counter() - t0
+        port["mid_run"] = {"value": 1.0 / dt_mid * scale, "unit": "iterations/s",
+                           "sample": f"one iteration after {half} selections (state taken from the GPU run), same rows, {dt_mid:.1f} s"}
     threads = min(os.cpu_count() or 1, 16)
     os.environ["OMP_NUM_THREADS"] = str(threads)
     t0 = time.perf_counter()
-    k = 40
-    idx, _, _ = ou.c_greedy(cols, n_var, np.ones(args.n_samp, np.uint8), k_max=k, omp=True)
+    idx, _, _ = ou.c_greedy(cols, n_var, np.ones(args.n_samp, np.uint8), k_max=40, omp=True)
     dt2 = time.perf_counter() - t0
     bitset = {"value": len(idx) / dt2 * scale, "unit": "iterations/s", "cores": threads, "kind": "port",
-              "sample": f"first {len(idx)} iterations, packed C bitset oracle with OpenMP, same sample, scaled the same way"}
+              "sample": f"first {len(idx)} iterations, packed C bitset oracle with OpenMP, same rows, scaled the same way"}
     return port, bitset
 
 
+def summarize(spec, label, world, steps, res, roofline, t_gen):
+    """Per-configuration record (the `also` entries and the core of the headline)."""
+    st = res["stats"]
+    gbps = st["algo_bytes"] * world * steps / res["elapsed"] / 1e9        # shards are equal-sized to within one sample
+    return {"workload": label, "value": res["iters"] / res["elapsed"], "unit": "iterations/s",
+            "ms_per_step": res["elapsed"] / max(1, steps) * 1e3, "steps": steps,
+            "iterations_per_step": res["iters"] // max(1, steps), "tot_captured": st["tot_captured"], "chunks": st["n_chunks"],
+            "algo_bytes_per_step": st["algo_bytes"] * world, "hbm_gbps_whole_loop": gbps,
+            "hbm_frac_whole_loop": gbps / (HBM_PEAK_GBPS * world), "device_loop_ms_per_step": res["loop_ms"] / max(1, steps),
+            "generator_s": round(t_gen, 3),
+            "roofline": None if roofline is None else {k: roofline[k] for k in ("frac", "achieved", "kernel", "launches", "avg_launch_us",
+                                                                               "algo_bytes_per_launch")}}
+
+
+def workload_label(spec):
+    k = select_count(spec)
+    return (f"synthetic {spec['n_var']} variants x {spec['n_samp']} samples bit-matrix, select "
+            f"{'all' if spec['select'] < 0 else k}{(', --af ' + spec['af_dtype']) if spec['af'] else ''}")
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -188,62 +311,32 @@ def main():
     import numpy as np
     from utmos_amd import device
 
+    spec = spec_of(args)
     n_total = args.n_samp
     first = rank * n_total // world
     n_local = (rank + 1) * n_total // world - first
-    n_dev = device.nat.device_count()
-    dev_index = local_rank % n_dev        # one GPU per rank on a full node; ranks share devices only on smaller test boxes
-    m = device.DeviceMatrix(n_total, device=dev_index, first_sample=first, n_local=n_local)
-    chunk_vars = args.chunk_vars or args.n_var
-    v0 = 0
-    t_gen = time.perf_counter()
-    while v0 < args.n_var:
-        nv = min(chunk_vars, args.n_var - v0)
-        c = m.add_chunk(nv)
-        m.synth_fill(c, seed=args.seed, first_var_global=v0)
-        if args.af:
-            _, af = device.synth_host(args.seed, nv, n_total, first_var_global=v0, want_cols=False)
-            # f64: full 53-bit mantissas, like the reference's ac/an quotients
-            m.set_af(c, af if args.af_dtype == "f32" else af.astype(np.float64) / 3.0)
-        v0 += nv
-    t_gen = time.perf_counter() - t_gen
-    exchange = "none"
-    host_staged = False
-    id_path = None
+    dev_index = local_rank % device.nat.device_count()   # one GPU per rank on a full node; ranks share devices only on smaller test boxes
+    m, t_gen = build_matrix(device, spec, dev_index, first, n_local)
+    k_sel = select_count(spec)
+    if args.decremental:
+        m.set_decremental(True, args.decr_threshold)
+    if args.af_estimate_scores:
+        m.set_af_exact_scores(False)
+
     transport = None
+    exchange = "none"
+    uid = None
     if world > 1:
-        # start-up over a local TCP socket (port published in the launch's rendezvous file).  Default exchange:
-        # every rank maps every other rank's columns and record mailboxes (hipIpc), the mappings are self-tested,
-        # and the loop then runs without any host or collective in it.  If that is not possible on every rank
-        # (or with --exchange rccl) the RCCL communicator carries the per-iteration exchange instead.
-        from utmos_amd.sharded import bootstrap, enable_p2p
+        # start-up over a local TCP socket (port, nonce and ncclUniqueId published in the launch's rendezvous file)
+        from utmos_amd.sharded import bootstrap, connect_shards
         transport, uid = bootstrap(rank, world, device.DeviceMatrix.comm_unique_id)
-        if args.exchange != "rccl" and os.environ.get("UTM_NO_P2P", "0") == "0":
-            enable_p2p(m, transport)
-        if not m.fused_mailboxes:
-            try:
-                m.comm_init(rank, world, uid)
-                ok = 1
-            except device.nat.NativeError as e:
-                sys.stderr.write(f"bench.py rank {rank}: RCCL communicator unavailable ({e})\n")
-                ok = 0
-            oks = [r[1] for r in transport.allgather((0.0, ok, 0))]
-            if not all(oks):
-                if any(oks):
-                    raise SystemExit("bench.py: RCCL came up on some ranks only")
-                host_staged = True      # last resort: records and winner columns through the host sockets
-        replica = m.stats()["p2p_replica_bytes"]
-        columns = (f"winner columns read from a one-time local copy of the other shards' columns ({replica / 1e9:.2f} GB)"
-                   if replica else "in-place column reads over hipIpc mappings (xGMI)")
-        boxes = "host shared-memory mailboxes" if getattr(m, "host_mailboxes", False) else "device mailboxes"
-        exchange = f"{boxes} + {columns}" if m.fused_mailboxes else (
-            "host-staged: records over TCP, winner column " + (columns if m.p2p else "through host memory")
-            if host_staged else
-            f"ncclAllGather of records, {columns}" if m.p2p else "ncclAllGather of records + columns")
+        try:
+            exchange = connect_shards(m, transport, uid, "auto" if args.exchange == "both" else args.exchange)
+        except RuntimeError as err:
+            raise SystemExit(f"bench.py rank {rank}: {err}")
     elif args.force_comm:
-        uid, id_path = rendezvous_id(rank, world, device.DeviceMatrix.comm_unique_id)
-        m.comm_init(rank, world, uid)
-        exchange = "ncclAllGather (single rank)"
+        m.comm_init(0, 1, device.DeviceMatrix.comm_unique_id())
+        exchange = "rccl"
 
     def sync_max(value):
         """Barrier + maximum over the ranks (host side: the ranks' loops are already drained)."""
@@ -251,65 +344,47 @@ def main():
             return value
         return max(r[0] for r in transport.allgather((float(value), 0, 0)))
 
-    k_sel = n_total if args.select < 0 else min(args.select, n_total)
-    if args.decremental:
-        m.set_decremental(True, args.decr_threshold)
-    if args.af_estimate_scores:
-        m.set_af_exact_scores(False)
-
-    def one_step():
-        m.reset()
-        if world > 1 and host_staged:
-            from utmos_amd.sharded import sharded_greedy
-            rows = list(sharded_greedy(m, transport, k_sel))
-            return (np.array([r[0] for r in rows], np.int64), np.array([r[1] for r in rows], np.int64),
-                    np.array([r[2] for r in rows], np.float64))
-        return m.run(k_sel)
-
-    for _ in range(args.warmup):
-        one_step()
-    sync_max(0.0)  # barrier (run() returns only after its stream has drained)
-    t0 = time.perf_counter()
-    iters = 0
-    loop_ms = 0.0
-    for _ in range(args.steps):
-        idx, new, _ = one_step()
-        iters += len(idx)
-        loop_ms += m.stats()["loop_ms"]
-    elapsed = time.perf_counter() - t0
-    elapsed = sync_max(elapsed)
-    st = m.stats()
-    algo_bytes_step = st["algo_bytes"]          # since the last reset = one step, this rank's shard
-    tot_captured = st["tot_captured"]
+    res = timed_steps(m, k_sel, args.steps, args.warmup, sync_max)
+    st = res["stats"]
+    idx, new, _ = res["rows"]
 
     roofline = None
     if not args.no_roofline_pass and not args.decremental:   # the roofline object describes the brute-force kernel only
-        # same step once more with every scoring launch bracketed by HIP events on its own stream
-        m.set_profile(True)
-        one_step()
-        ps = m.stats()
-        m.set_profile(False)
-        if ps["score_ms"] > 0:
-            achieved = ps["algo_bytes"] / (ps["score_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                        "kernel": "k_score_afs (+k_score_afq for the first launches)" if args.af else "k_score_int",
-                        "launches": ps["score_launches"],
-                        "avg_launch_us": ps["score_ms"] * 1e3 / max(1, ps["score_launches"]),
-                        "algo_bytes_per_launch": ps["algo_bytes"] / max(1, ps["score_launches"]),
-                        "rank": rank}
+        roofline = roofline_pass(m, k_sel, args.af, rank)
+
+    # N > 1: the same steps again through north_star's RCCL protocol, measured beside the default exchange
+    also_exchange = None
+    if world > 1 and args.exchange == "both" and exchange == "mailboxes":
+        m.p2p_use_mailboxes(False)
+        err = None
+        try:
+            m.comm_init(rank, world, uid)
+        except device.nat.NativeError as exc:
+            err = exc
+        if transport.agree(err is None):
+            r2 = timed_steps(m, k_sel, args.steps, min(args.warmup, 1), sync_max)
+            s2 = r2["stats"]
+            same = bool(len(r2["rows"][0]) == len(idx) and (r2["rows"][0] == idx).all() and (r2["rows"][1] == new).all())
+            also_exchange = {"rccl": {"value": r2["iters"] / r2["elapsed"], "unit": "iterations/s",
+                                      "ms_per_step": r2["elapsed"] / max(1, args.steps) * 1e3, "exchange": m.exchange(),
+                                      "rccl_ranks": s2["rccl_ranks"], "rows_match_default_exchange": same,
+                                      "protocol": "per iteration: ncclAllGather of 64-byte records, ncclBroadcast of the winner's column from its owner"}}
+        else:
+            also_exchange = {"rccl": {"error": f"RCCL communicator unavailable on some rank ({err})"}}
+        m.p2p_use_mailboxes(True)             # back to the headline's exchange for the check below
 
     # PMC traffic cannot be read from inside the process: two counter passes in child processes (N = 1), else the
     # passes recorded under profiles/ for the default configurations (tools/summarize_profile.py)
     if roofline is not None and args.pmc_traffic != "off":
         # (the child holds a second copy of the matrix next to this process's: only when that is a small part of the HBM)
         fits_twice = args.n_var * n_total / 8 < 0.25 * device.nat.device_memory(dev_index)[1]
-        live = live_pmc_traffic(args) if args.pmc_traffic == "live" and world == 1 and fits_twice else None
+        extra = ["--af-estimate-scores"] if args.af_estimate_scores else []
+        live = live_pmc_traffic(spec, extra) if args.pmc_traffic == "live" and world == 1 and fits_twice else None
         if live is not None:
             roofline["traffic"], roofline["traffic_launches"], roofline["traffic_source"] = live
         elif args.n_var == 10_000_000 and n_total == 2504 and args.select < 0 and world == 1 \
                 and not args.chunk_vars and (not args.af or args.af_dtype == "f32"):
-            rec = os.path.join(ROOT, "profiles", "r01_cfg3_pmc_hbm.json" if args.af else "r01_cfg2_pmc_hbm.json")
+            rec = os.path.join(ROOT, "profiles", "r02_cfg3_pmc_hbm.json" if args.af else "r02_cfg2_pmc_hbm.json")
             if os.path.exists(rec):
                 with open(rec) as fh:
                     roofline["traffic"] = json.load(fh)["hbm_bytes_per_launch_mean"]
@@ -319,64 +394,65 @@ def main():
     # from this very run that the sharded exchange decides exactly like a single GPU
     sharded_check = None
     if (world > 1 or args.force_comm) and rank == 0 and not args.no_sharded_check:
-        with device.DeviceMatrix(n_total, device=dev_index) as solo:
-            v0 = 0
-            while v0 < args.n_var:
-                nv = min(chunk_vars, args.n_var - v0)
-                c = solo.add_chunk(nv)
-                solo.synth_fill(c, seed=args.seed, first_var_global=v0)
-                if args.af:
-                    _, af = device.synth_host(args.seed, nv, n_total, first_var_global=v0, want_cols=False)
-                    solo.set_af(c, af if args.af_dtype == "f32" else af.astype(np.float64) / 3.0)
-                v0 += nv
-            s_idx, s_new, s_score = solo.run(k_sel)
+        solo, _ = build_matrix(device, spec, dev_index)
+        with solo:
+            s_idx, s_new, _ = solo.run(k_sel)
         sharded_check = bool(len(s_idx) == len(idx) and (s_idx == idx).all() and (s_new == new).all())
         if not sharded_check:
             sys.stderr.write("bench.py: SHARDED RESULT DIFFERS FROM THE SINGLE-GPU RESULT\n")
 
-    cpu = bitset = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, bitset = cpu_baseline(args, device)
-
-    if id_path and rank == 0:
-        try:
-            os.remove(id_path)
-        except OSError:
-            pass
+    head = summarize(spec, workload_label(spec), world, args.steps, res, roofline, t_gen)
+    final_stats = m.stats()
+    sync_max(0.0)          # nobody unmaps its columns while a peer may still be finishing
+    if transport is not None:
+        transport.close()
+    m.close()
     if rank != 0:
-        sync_max(0.0)      # nobody unmaps its columns while a peer may still be finishing
-        if transport is not None:
-            transport.close()
-        m.close()
         return
-    sync_max(0.0)
-    value = iters / elapsed
-    whole_loop_gbps = algo_bytes_step * world * args.steps / elapsed / 1e9   # shards are equal-sized to within one sample
+
+    # N = 1, default workload: the other single-GPU BASELINE configurations, one step each
+    also = None
+    if world == 1 and not args.explicit_shape and not args.no_also and not args.force_comm:
+        also = {}
+        for name in ALSO:
+            s2 = dict(af=False, af_dtype="f32", chunk_vars=0, seed=args.seed)
+            s2.update(WORKLOADS[name][1])
+            try:
+                m2, t2 = build_matrix(device, s2, dev_index)
+                with m2:
+                    k2 = select_count(s2)
+                    r2 = timed_steps(m2, k2, 1, 1 if name in ("cfg1", "cfg3") else 0, lambda v: v)
+                    roof2 = roofline_pass(m2, k2, s2["af"])
+                also[name] = summarize(s2, WORKLOADS[name][0], 1, 1, r2, roof2, t2)
+            except device.nat.NativeError as exc:      # e.g. a GPU with less HBM than the 156 GB of cfg5
+                also[name] = {"workload": WORKLOADS[name][0], "error": str(exc)}
+
+    cpu = bitset = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu, bitset = cpu_baseline(args, device, idx)
+
     line = {
-        "metric": "greedy iterations/sec + achieved HBM GB/s, 10M variants \u00d7 2.5k samples",   # BASELINE.json's string
-        "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "strong",
+        "metric": METRIC, "value": head["value"], "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": (args.af_dtype + "+u64") if args.af else "u64", "data": "synthetic",
-        "config": {"workload": f"synthetic {args.n_var} variants x {n_total} samples bit-matrix, select "
-                               f"{'all' if args.select < 0 else k_sel}{(', --af ' + args.af_dtype) if args.af else ''}",
-                   "n_var": args.n_var, "n_samp": n_total, "iterations_per_step": iters // max(1, args.steps),
-                   "tot_captured": tot_captured, "chunks": st["n_chunks"], "seed": args.seed,
-                   "sharding": f"sample axis over {world} GPU(s); per-iteration exchange: {exchange}" if world > 1 else "none",
-                   "generator_s": round(t_gen, 3), "af_verified_parallel": st["af_fixed_point"] if args.af else None},
+        "config": {"workload": head["workload"], "n_var": args.n_var, "n_samp": n_total,
+                   "iterations_per_step": head["iterations_per_step"], "tot_captured": head["tot_captured"], "chunks": head["chunks"],
+                   "seed": args.seed, "sharding": f"sample axis over {world} GPU(s)" if world > 1 else "none",
+                   "generator_s": head["generator_s"], "af_verified_parallel": st["af_fixed_point"] if args.af else None},
+        "exchange": exchange, "rccl_ranks": final_stats["rccl_ranks"] if exchange == "rccl" else None,
+        "p2p_replica_bytes": final_stats["p2p_replica_bytes"] if world > 1 else None,
+        "also_exchange": also_exchange,
         "scoring": "decremental after the first passes (bytes = what this variant actually reads; NOT the brute-force "
                    "roofline metric)" if args.decremental else "brute force: every selectable column re-read every iteration",
         "decremental_iterations_per_step": st["decr_iterations"] if args.decremental else 0,
         "decremental_interleaved_copy_bytes": st["decr_interleaved_bytes"] if args.decremental else 0,
-        "brute_force_equivalent_gbps": st["brute_force_bytes"] * world * args.steps / elapsed / 1e9,
-        "hbm_gbps_whole_loop": whole_loop_gbps, "hbm_frac_whole_loop": whole_loop_gbps / (HBM_PEAK_GBPS * world),
-        "device_loop_ms_per_step": loop_ms / max(1, args.steps),
+        "brute_force_equivalent_gbps": st["brute_force_bytes"] * world * args.steps / res["elapsed"] / 1e9,
+        "hbm_gbps_whole_loop": head["hbm_gbps_whole_loop"], "hbm_frac_whole_loop": head["hbm_frac_whole_loop"],
+        "device_loop_ms_per_step": head["device_loop_ms_per_step"],
         "sharded_rows_match_single_gpu": sharded_check,
-        "roofline": roofline, "cpu_baseline": cpu, "cpu_bitset_baseline": bitset,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_bitset_baseline": bitset, "also": also,
     }
     print(json.dumps(line))
-    if transport is not None:
-        transport.close()
-    m.close()
 
 
 if __name__ == "__main__":

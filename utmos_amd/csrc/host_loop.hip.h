@@ -64,7 +64,7 @@ static void launch_apply_pending(utm_ctx *c)
 {
     for (auto &ch : c->chunks)
         hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
-                           ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
+                           ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, 1);
 }
 
 // Sequential AF scoring of every selectable sample: covered is brought up to date first, then one lane per
@@ -169,7 +169,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, bool fuse_pi
             const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
             const double af_switch = sw && *sw ? atof(sw) : 0.2;
             const bool af_dense = (double)c->captured_seen < af_switch * (double)c->n_var_total;
-            if (c->p2p && !c->replicated) launch_apply_pending(c);
+            if (remote_reads(c)) launch_apply_pending(c);
             for (auto &ch : c->chunks) {
                 if (af_dense) launch_score_af_dense(c, ch, a_ub);
                 else launch_score_streaming(c, ch, a_ub);
@@ -182,7 +182,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, bool fuse_pi
             for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub, /*delta=*/true);
         }
     } else {
-        if (c->p2p && !c->replicated) launch_apply_pending(c);  // remote column: read it once, not once per workgroup
+        if (remote_reads(c)) launch_apply_pending(c);  // remote column: read it once, not once per workgroup
         static const int fuse_env = tune_env("UTM_FUSE_PICK", 1);
         IntLaunch how;
         how.by_pos = !by_sample;
@@ -237,15 +237,20 @@ static int enqueue_score_decr(utm_ctx *c)
     return UTM_OK;
 }
 
-// Algorithmic HBM bytes of one iteration with `a` selectable local samples:
-// active columns + covered read + winner column re-read + covered write (+ AF values).
-static i64 iteration_bytes(const utm_ctx *c, u64 a)
+// Algorithmic HBM bytes of one scoring pass with `a` selectable local samples (SURVEY.md §8d "the
+// bytes that variant actually has to read"): active columns + covered read + winner column re-read + covered write;
+//   UTM_PASS_AF_FULL   + the per-variant AF table (a full AF pass, and every pass of the sequential AF kernel);
+//   UTM_PASS_AF_DELTA  + the newly-covered mask written once and read once; the AF values such a pass gathers are
+//                        counted from the counts' decrease (utm_run) -- it never reads the table as a whole.
+enum { UTM_PASS_PLAIN = 0, UTM_PASS_AF_FULL = 1, UTM_PASS_AF_DELTA = 2 };
+static i64 iteration_bytes(const utm_ctx *c, u64 a, int kind = -1)
 {
+    if (kind < 0) kind = c->af_mode != UTM_AF_NONE ? UTM_PASS_AF_FULL : UTM_PASS_PLAIN;
     i64 b = 0;
     for (auto &ch : c->chunks) {
         b += (i64)((a + 3) * ch.w * 8);
-        if (c->af_mode == UTM_AF_F32) b += (i64)ch.n_var * 4;
-        if (c->af_mode == UTM_AF_F64) b += (i64)ch.n_var * 8;
+        if (kind == UTM_PASS_AF_FULL) b += (i64)ch.n_var * (c->af_mode == UTM_AF_F64 && !c->af_fixed ? 8 : 4);
+        if (kind == UTM_PASS_AF_DELTA) b += (i64)(2 * ch.w * 8);
     }
     return b;
 }
@@ -284,20 +289,18 @@ static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
         // device-side exchange: post this shard's record into every shard's mailbox, wait for theirs, decide
         hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, c->stream, a);  // pick, post, collect, decide
     } else if (c->comm) {
+        // RCCL exchange, first half: every shard's 64-byte record to every shard (one ncclAllGather, in place), then the
+        // same decision everywhere.  The second half -- the winner's column, ncclBroadcast from its owner -- needs the
+        // owner's rank on the host: utm_run syncs after every iteration in this mode (rccl_exchange) and issues it.
         hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, c->stream, a);
-        u64 *slot = c->d_xbuf + (u64)c->rank * c->xbuf_slot_words;
-        if (!c->p2p)
-            for (auto &ch : c->chunks)
-                hipLaunchKernelGGL(k_pack, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
-                                   slot + UTM_HDR_WORDS + ch.off, ch.cols, ch.wp, c->d_st, c->d_act);
         HIP_TRY(hipGetLastError());
-        // one collective per iteration: every shard's record (and, without P2P mappings, its candidate column), in place
-        NCCL_TRY(g_rccl.AllGather(slot, c->d_xbuf, c->xbuf_slot_words, ncclUint64, c->comm, c->stream));
+        NCCL_TRY(g_rccl.AllGather(c->d_xbuf + (u64)c->rank * UTM_HDR_WORDS, c->d_xbuf, UTM_HDR_WORDS, ncclUint64, c->comm, c->stream));
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, a);
-    } else if (c->n_ranks == 1) {
+    } else if (c->n_ranks == 1 && c->n_local == c->n_total) {
         hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(pick_threads), 0, c->stream, a);
     } else {
-        return fail(UTM_ESTATE, "sharded context without a fused exchange: use utm_local_best / utm_apply_records, or enable the mailboxes / RCCL");
+        return fail(UTM_ESTATE, "this context holds a shard of the samples and has no exchange: enable the record mailboxes "
+                                "(utm_p2p_import + utm_p2p_use_mailboxes) or RCCL (utm_comm_init), or drive it with utm_local_best / utm_apply_records");
     }
     HIP_TRY(hipGetLastError());
     return UTM_OK;
@@ -345,7 +348,8 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     // only needs the stop flag (256: a boundary costs an idle device for two round trips)
     static const int batch_env = tune_env("UTM_BATCH", 0);
     static const int decr_first = std::max(1, tune_env("UTM_DECR_FIRST_BATCH", 8));
-    const int batch = batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
+    // (RCCL exchange: one iteration per sync -- the column broadcast's root is only known on the host after it)
+    const int batch = rccl_exchange(c) ? 1 : batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
     i64 enq = 0;
     while (enq < k_max && !c->finished) {
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
@@ -360,16 +364,28 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         const bool decr = c->decr_enabled && c->keep_valid && c->last_new >= 0 && (c->af_mode == UTM_AF_NONE || c->af_fixed) &&
                           (double)c->last_new <= (c->decr_threshold > 0 ? c->decr_threshold : c->decr_interleaved ? 1.0 : 0.2) *
                                                      (double)c->col_words;
+        // AF, verified-parallel: the first pass after anything invalidated the accumulators is a full one, the others
+        // are delta passes (enqueue_score); the byte accounting below tells them apart
+        const bool af_par = c->af_mode != UTM_AF_NONE && c->af_fixed && !decr;
+        const bool first_is_full = af_par && !c->keep_valid;
         for (i64 j = 0; j < n; ++j) {
             bool picked = false;
             if (decr) TRY(enqueue_score_decr(c));
-            else TRY(enqueue_score(c, false, /*fuse_pick=*/c->n_ranks == 1 && !c->comm, &picked));
+            else TRY(enqueue_score(c, false, /*fuse_pick=*/c->n_ranks == 1 && c->n_local == c->n_total && !c->comm, &picked));
             if (!picked) TRY(enqueue_pick_and_exchange(c, decr));
+            if (af_par && j == 0 && first_is_full) hipLaunchKernelGGL(k_count_sum, dim3(1), dim3(1024), 0, c->stream, c->d_st, c->d_act, c->d_cnt, 1);
             if (c->n_ranks == 1 && c->active_ub > 0) c->active_ub -= 1;  // exact while the loop is alive
         }
+        if (af_par) hipLaunchKernelGGL(k_count_sum, dim3(1), dim3(1024), 0, c->stream, c->d_st, c->d_act, c->d_cnt, 0);
         enq += n;
         const i64 before = c->iter;
         TRY(sync_state(c));
+        if (rccl_exchange(c) && c->iter > before && !c->finished) {
+            // second half of the RCCL exchange: the winner's column from its owner into every shard's winner-column
+            // buffer, where the next scoring pass ORs it into covered (select.py:100 on every replica)
+            const int owner = c->h_st->prev_rank;
+            TRY(broadcast_column(c, owner, owner == c->rank ? c->h_st->prev_gidx - (i64)c->first : -1));
+        }
         // bytes: iterations that were actually scored in this batch (rows + a terminating empty pass); the
         // local selectable count falls from a0 to a1 over the batch's rows (by one per row on a single shard)
         const i64 rows = c->iter - before;
@@ -377,10 +393,27 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         const unsigned a1 = c->active_ub;
         for (i64 j = 0; j < passes; ++j) {
             const u64 drop = rows > 0 ? (u64)(a0 - a1) * (u64)std::min(j, rows) / (u64)rows : 0;
-            const i64 full = iteration_bytes(c, a0 - drop);
+            const int kind = !af_par ? -1 : (j == 0 && first_is_full) ? UTM_PASS_AF_FULL : UTM_PASS_AF_DELTA;
+            const i64 full = iteration_bytes(c, a0 - drop, kind);
             c->brute_bytes += full;
             if (!decr) c->algo_bytes += full;
         }
+        if (af_par && rows > 0) {
+            // AF values the delta passes of this batch gathered = how far the selectable samples' counts fell, less
+            // what left with the winners themselves (4 bytes per fixed-point table entry)
+            const i64 skip = first_is_full ? 1 : 0;
+            std::vector<i64> gains((size_t)std::max<i64>(0, rows - skip));
+            if (!gains.empty()) HIP_TRY(copy_sync(c, gains.data(), c->d_res_new + before + skip, gains.size() * 8, hipMemcpyDeviceToHost));
+            i64 left_with_winners = 0;
+            for (i64 g : gains) left_with_winners += g;
+            const u64 prev = first_is_full ? c->h_st->cnt_sum_base : c->cnt_sum_prev;
+            const i64 gathered = (i64)prev - (i64)c->h_st->cnt_sum - left_with_winners;
+            if (gathered > 0) {
+                c->algo_bytes += gathered * 4;
+                c->brute_bytes += gathered * 4;
+            }
+        }
+        if (af_par) c->cnt_sum_prev = c->h_st->cnt_sum;
         if (decr) {
             // what the decremental iterations had to touch: winner column + covered (read), the list (written
             // once, read once), covered words rewritten, and one word per (selectable sample, listed word)
@@ -457,7 +490,7 @@ static int flush_pending(utm_ctx *c)
 {
     for (auto &ch : c->chunks)
         hipLaunchKernelGGL(k_apply_pending, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
-                           ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st);
+                           ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, 0);
     HIP_TRY(hipGetLastError());
     return UTM_OK;
 }
@@ -494,6 +527,15 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->decr_iterations = c->decr_iterations;
     out->brute_force_bytes = c->brute_bytes;
     out->p2p_replica_bytes = (i64)c->replica_bytes;
+    out->exchange = c->n_local == c->n_total && !c->comm ? UTM_EXCHANGE_NONE
+                    : (c->n_ranks > 1 && c->mbox_ok)     ? UTM_EXCHANGE_MAILBOX
+                    : c->comm                            ? UTM_EXCHANGE_RCCL
+                                                         : UTM_EXCHANGE_CALLER;
+    out->rccl_ranks = 0;
+    if (c->comm) {
+        int n = 0;
+        if (g_rccl.CommCount(c->comm, &n) == ncclSuccess) out->rccl_ranks = n;
+    }
     out->decr_interleaved_bytes = c->decr_interleaved ? (i64)(c->col_words * interleaved_stride(c) * 8) : 0;
     return UTM_OK;
 }

@@ -7,7 +7,9 @@ extern "C" int utm_add_chunk(utm_ctx *c, uint64_t n_var, int32_t *chunk)
 {
     CTX(c);
     if (n_var == 0) return fail(UTM_EINVAL, "empty chunk");
-    if (c->comm) return fail(UTM_ESTATE, "chunks must be added before utm_comm_init");
+    // a count word keeps bits 40.. for the tile-arrival count of a fused launch (k_score_int): counts stay below 2^40
+    if (c->n_var_total + n_var >= (1ull << 40)) return fail(UTM_EINVAL, "more than 2^40 variants in one matrix");
+    if (c->exported) return fail(UTM_ESTATE, "chunks must be added before the columns are exported to other shards");
     Chunk ch;
     ch.n_var = n_var;
     ch.w = (n_var + 63) / 64;
@@ -22,7 +24,6 @@ extern "C" int utm_add_chunk(utm_ctx *c, uint64_t n_var, int32_t *chunk)
     c->chunks.push_back(std::move(ch));
     c->n_var_total += n_var;
     c->col_words += c->chunks.back().wp;
-    c->slot_words = UTM_HDR_WORDS + c->col_words;
     c->prepared = false;
     c->dirty_tables = true;
     c->varcount_valid = false;

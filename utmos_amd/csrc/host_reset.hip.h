@@ -5,15 +5,25 @@
 // ---------------------------------------------------------------------------------------- loop set-up
 static int ensure_xbuf(utm_ctx *c, int n_ranks)
 {
-    // records only, unless whole columns travel through the slots (column all-gather / host-staged without P2P)
-    const u64 slot = ((n_ranks == 1 && !c->comm) || c->p2p) ? UTM_HDR_WORDS : c->slot_words;
-    if (c->d_xbuf && c->xbuf_ranks == n_ranks && c->xbuf_slot_words == slot) return UTM_OK;
+    if (c->d_xbuf && c->xbuf_ranks == n_ranks) return UTM_OK;
     (void)hipFree(c->d_xbuf);
     c->d_xbuf = nullptr;
-    HIP_TRY(hipMalloc(&c->d_xbuf, (size_t)n_ranks * slot * 8));
-    HIP_TRY(hipMemsetAsync(c->d_xbuf, 0, (size_t)n_ranks * slot * 8, c->stream));  // same stream as every later use
+    HIP_TRY(hipMalloc(&c->d_xbuf, (size_t)n_ranks * UTM_HDR_WORDS * 8));
+    HIP_TRY(hipMemsetAsync(c->d_xbuf, 0, (size_t)n_ranks * UTM_HDR_WORDS * 8, c->stream));  // same stream as every later use
     c->xbuf_ranks = n_ranks;
-    c->xbuf_slot_words = slot;
+    return UTM_OK;
+}
+
+// Room for one whole column delivered by the exchange (RCCL broadcast / utm_apply_records' winner_col).
+static int ensure_wincol(utm_ctx *c)
+{
+    if (c->d_wincol && c->wincol_words == c->col_words) return UTM_OK;
+    (void)hipFree(c->d_wincol);
+    c->d_wincol = nullptr;
+    c->wincol_words = 0;
+    HIP_TRY(hipMalloc(&c->d_wincol, (size_t)c->col_words * 8));
+    HIP_TRY(hipMemsetAsync(c->d_wincol, 0, (size_t)c->col_words * 8, c->stream));
+    c->wincol_words = c->col_words;
     return UTM_OK;
 }
 
@@ -73,6 +83,24 @@ static int ensure_interleaved(utm_ctx *c)
     return UTM_OK;
 }
 
+// One whole column from its owner to every shard's winner-column buffer: ncclBroadcast, one call per chunk in
+// one group (the owner sends straight from its matrix).  local_col = the column's local index on the owner, else -1.
+static int broadcast_column(utm_ctx *c, int owner, i64 local_col)
+{
+    TRY(ensure_wincol(c));
+    NCCL_TRY(g_rccl.GroupStart());
+    for (auto &ch : c->chunks) {
+        const u64 *send = owner == c->rank ? ch.cols + (u64)local_col * ch.wp : c->d_wincol + ch.off;
+        ncclResult_t r = g_rccl.Broadcast(send, c->d_wincol + ch.off, ch.wp, ncclUint64, owner, c->comm, c->stream);
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            return fail(UTM_ECOMM, "ncclBroadcast(column from rank %d) -> %s", owner, g_rccl.GetErrorString(r));
+        }
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return UTM_OK;
+}
+
 extern "C" int utm_reset(utm_ctx *c)
 {
     CTX(c);
@@ -90,12 +118,36 @@ extern "C" int utm_reset(utm_ctx *c)
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_fscore, 0, (size_t)c->n_local * 8, c->stream));
-    for (auto &ch : c->chunks) {
-        HIP_TRY(hipMemsetAsync(ch.covered, 0, ch.wp * 8, c->stream));
-        // samples that start out used cover their variants from the first iteration (select.py:36-39)
-        for (uint32_t s = 0; s < c->n_local; ++s)
-            if (c->h_state[c->first + s] == 0)
-                hipLaunchKernelGGL(k_or_column, dim3(256), dim3(256), 0, c->stream, ch.covered, ch.cols + (u64)s * ch.wp, ch.wp);
+    for (auto &ch : c->chunks) HIP_TRY(hipMemsetAsync(ch.covered, 0, ch.wp * 8, c->stream));
+    // Samples that start out used cover their variants from the first iteration (select.py:36-39) -- on every
+    // shard's covered replica, whoever owns the column: local columns are OR-ed in place; a peer's column is read
+    // through its mapping (P2P) or broadcast by its owner (RCCL; every shard walks the same list, so the calls
+    // match); a context with neither cannot know a remote column and says so.
+    for (uint32_t g = 0; g < c->n_total; ++g) {
+        if (c->h_state[g] != 0) continue;
+        if (g >= c->first && g < c->first + c->n_local) {
+            for (auto &ch : c->chunks)
+                hipLaunchKernelGGL(k_or_column, dim3(256), dim3(256), 0, c->stream, ch.covered, ch.cols + (u64)(g - c->first) * ch.wp, ch.wp);
+            if (!c->comm || c->p2p || c->n_ranks == 1) continue;
+        }
+        if (c->n_local == c->n_total) continue;
+        int owner = -1;
+        for (size_t r = 0; r < c->rank_first.size(); ++r)
+            if (g >= c->rank_first[r] && g < c->rank_first[r] + c->rank_local[r]) owner = (int)r;
+        if (c->p2p && owner >= 0) {
+            if (owner == c->rank) continue;
+            for (auto &ch : c->chunks)
+                hipLaunchKernelGGL(k_or_column_remote, dim3(256), dim3(256), 0, c->stream, ch.covered,
+                                   ch.h_peer_cols[owner] + (u64)(g - c->rank_first[owner]) * ch.wp, ch.wp);
+        } else if (c->comm && owner >= 0) {
+            TRY(broadcast_column(c, owner, owner == c->rank ? (i64)(g - c->first) : -1));
+            if (owner != c->rank)
+                for (auto &ch : c->chunks)
+                    hipLaunchKernelGGL(k_or_column, dim3(256), dim3(256), 0, c->stream, ch.covered, c->d_wincol + ch.off, ch.wp);
+        } else {
+            return fail(UTM_ESTATE, "sample %u starts out used but belongs to another shard: map the shards' columns (utm_p2p_import) or "
+                                    "initialise RCCL (utm_comm_init) first, so that its column can reach this shard's covered mask", g);
+        }
     }
     HIP_TRY(hipGetLastError());
     IterState st;
@@ -187,7 +239,7 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     // (a shard's record is compared with other shards' records: there the score has to be exact)
     a.af_skip_single = (!c->af_exact_scores && c->n_local == c->n_total) ? 1 : 0;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
-    a.slot_words = c->xbuf_slot_words;
+    a.remote_winner_test = c->remote_winner_test ? 1 : 0;
     a.res_idx = c->d_res_idx;
     a.res_new = c->d_res_new;
     a.res_score = c->d_res_score;

@@ -25,8 +25,7 @@ extern "C" int utm_local_best(utm_ctx *c, utm_record *rec)
     enqueue_candidates(c, a);
     hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
-    const u64 slot = c->xbuf_slot_words;
-    HIP_TRY(hipMemcpyAsync(rec, c->d_xbuf + (u64)c->rank * slot, sizeof *rec, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(rec, c->d_xbuf + (u64)c->rank * UTM_HDR_WORDS, sizeof *rec, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->algo_bytes += iteration_bytes(c, c->active_ub);
     c->scored += 1;
@@ -53,21 +52,22 @@ extern "C" int utm_apply_records(utm_ctx *c, const utm_record *recs, int32_t n_r
     if (c->comm) return fail(UTM_ESTATE, "context exchanges through RCCL; use utm_step/utm_run");
     TRY(ensure_prepared(c));
     TRY(ensure_xbuf(c, n_ranks));
-    const u64 slot = c->xbuf_slot_words;
-    // who wins (same rule as decide()) -- only needed to place the winner's column in its slot
+    // who wins (same rule as decide()) -- only needed to know whether the winner's column has to come with the call
     int win = -1;
     for (int r = 0; r < n_ranks; ++r) {
         if (recs[r].idx < 0) continue;
         if (win < 0 || recs[r].score > recs[win].score || (recs[r].score == recs[win].score && recs[r].idx < recs[win].idx)) win = r;
     }
-    for (int r = 0; r < n_ranks; ++r)
-        HIP_TRY(hipMemcpyAsync(c->d_xbuf + (u64)r * slot, &recs[r], sizeof(utm_record), hipMemcpyHostToDevice, c->stream));
-    if (win >= 0 && winner_col && !c->p2p) {
-        if (n_ranks == 1) return fail(UTM_EINVAL, "winner_col given for a single shard");
-        HIP_TRY(hipMemcpyAsync(c->d_xbuf + (u64)win * slot + UTM_HDR_WORDS, winner_col, c->col_words * 8, hipMemcpyHostToDevice, c->stream));
-    } else if (win >= 0 && !c->p2p) {
+    HIP_TRY(hipMemcpyAsync(c->d_xbuf, recs, (size_t)n_ranks * sizeof(utm_record), hipMemcpyHostToDevice, c->stream));
+    if (win >= 0 && !c->p2p) {
         const i64 g = recs[win].idx;
-        if (g < (i64)c->first || g >= (i64)c->first + c->n_local) return fail(UTM_EINVAL, "winner %lld is remote but winner_col is NULL", (long long)g);
+        const bool local = g >= (i64)c->first && g < (i64)c->first + c->n_local;
+        if (winner_col && n_ranks == 1) return fail(UTM_EINVAL, "winner_col given for a single shard");
+        if (!local && !winner_col) return fail(UTM_EINVAL, "winner %lld is remote but winner_col is NULL", (long long)g);
+        if (!local) {
+            TRY(ensure_wincol(c));
+            HIP_TRY(hipMemcpyAsync(c->d_wincol, winner_col, c->col_words * 8, hipMemcpyHostToDevice, c->stream));
+        }
     }
     const i64 before = c->iter;
     hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, pick_args(c));
@@ -141,6 +141,7 @@ static void p2p_close(utm_ctx *c)
         ch.ipc_opened.clear();
         (void)hipFree(ch.d_peer_cols);
         ch.d_peer_cols = nullptr;
+        ch.h_peer_cols.clear();
         (void)hipFree(ch.replica);
         ch.replica = nullptr;
     }
@@ -248,7 +249,10 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
     for (size_t k = 0; k < c->chunks.size(); ++k) {
         HIP_TRY(hipMalloc(&c->chunks[k].d_peer_cols, (size_t)n_ranks * sizeof(u64 *)));
         HIP_TRY(copy_sync(c, c->chunks[k].d_peer_cols, table[k].data(), (size_t)n_ranks * sizeof(u64 *), hipMemcpyHostToDevice));
+        c->chunks[k].h_peer_cols = table[k];
     }
+    c->rank_first = firsts;
+    c->rank_local = locals;
     if (all_boxes) {
         HIP_TRY(hipMalloc(&c->d_peer_mbox, (size_t)n_ranks * sizeof(Mailbox *)));
         HIP_TRY(copy_sync(c, c->d_peer_mbox, boxes.data(), (size_t)n_ranks * sizeof(Mailbox *), hipMemcpyHostToDevice));
@@ -257,68 +261,6 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
     c->rank = rank;
     c->n_ranks = n_ranks;
     c->prepared = false;  // exchange slots shrink to records
-    return UTM_OK;
-}
-
-// The same end state as utm_p2p_import + replication, without hipIpc: the caller gathered every shard's columns in
-// host memory (one array per chunk: n_total columns of `stride_words[k]` words, e.g. a shared-memory file each
-// shard's process wrote its own columns into); the other shards' columns are uploaded into a local copy and the
-// pending-column table points there.  For nodes where device memory cannot be shared between processes: the loop
-// then needs nothing but the record exchange (utm_p2p_host_mailboxes).  Fails with UTM_ENOMEM when the copy does
-// not fit -- the caller falls back to a collective that carries the columns.
-extern "C" int utm_p2p_replica_from_host(utm_ctx *c, int32_t rank, int32_t n_ranks, const uint32_t *firsts,
-                                         const uint32_t *locals, const uint64_t *const *chunk_cols,
-                                         const uint64_t *stride_words)
-{
-    CTX(c);
-    if (!firsts || !locals || !chunk_cols || !stride_words || n_ranks < 1 || rank < 0 || rank >= n_ranks)
-        return fail(UTM_EINVAL, "bad arguments");
-    if (n_ranks > UTM_MAX_RANKS) return fail(UTM_EINVAL, "at most %d shards", UTM_MAX_RANKS);
-    if (firsts[rank] != c->first || locals[rank] != c->n_local) return fail(UTM_EINVAL, "this shard's range differs from the table");
-    u64 covered_samples = 0;
-    for (int r = 0; r < n_ranks; ++r) covered_samples += locals[r];
-    if (covered_samples != c->n_total) return fail(UTM_EINVAL, "the shards' ranges do not add up to %u samples", c->n_total);
-    for (size_t k = 0; k < c->chunks.size(); ++k)
-        if (!chunk_cols[k] || stride_words[k] < c->chunks[k].w) return fail(UTM_EINVAL, "chunk %zu: no columns / stride too short", k);
-    p2p_close(c);
-    const u64 others = c->n_total - c->n_local;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if ((u64)free_b < others * c->col_words * 8 + (8ull << 30)) return fail(UTM_ENOMEM, "no room for a copy of the other shards' columns");
-    std::vector<std::vector<const u64 *>> table(c->chunks.size(), std::vector<const u64 *>(n_ranks, nullptr));
-    for (size_t k = 0; k < c->chunks.size(); ++k) {
-        Chunk &ch = c->chunks[k];
-        if (others && hipMalloc(&ch.replica, (size_t)(others * ch.wp * 8)) != hipSuccess) {
-            (void)hipGetLastError();
-            p2p_close(c);
-            return fail(UTM_ENOMEM, "no room for a copy of the other shards' columns");
-        }
-        u64 off = 0;
-        for (int r = 0; r < n_ranks; ++r) {
-            if (r == rank) { table[k][r] = ch.cols; continue; }
-            if (locals[r] == 0) { table[k][r] = ch.replica + off; continue; }
-            HIP_TRY(hipMemsetAsync(ch.replica + off, 0, (size_t)locals[r] * ch.wp * 8, c->stream));  // the padding words
-            HIP_TRY(hipMemcpy2DAsync(ch.replica + off, ch.wp * 8, chunk_cols[k] + (u64)firsts[r] * stride_words[k],
-                                     stride_words[k] * 8, ch.w * 8, locals[r], hipMemcpyHostToDevice, c->stream));
-            table[k][r] = ch.replica + off;
-            off += (u64)locals[r] * ch.wp;
-        }
-    }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<unsigned> f(firsts, firsts + n_ranks);
-    HIP_TRY(hipMalloc(&c->d_peer_first, (size_t)n_ranks * 4));
-    HIP_TRY(copy_sync(c, c->d_peer_first, f.data(), (size_t)n_ranks * 4, hipMemcpyHostToDevice));
-    for (size_t k = 0; k < c->chunks.size(); ++k) {
-        HIP_TRY(hipMalloc(&c->chunks[k].d_peer_cols, (size_t)n_ranks * sizeof(u64 *)));
-        HIP_TRY(copy_sync(c, c->chunks[k].d_peer_cols, table[k].data(), (size_t)n_ranks * sizeof(u64 *), hipMemcpyHostToDevice));
-    }
-    c->replicated = true;
-    c->replica_bytes = others * c->col_words * 8;
-    c->exported = true;  // the peers hold copies: the columns must not change any more
-    c->p2p = true;
-    c->rank = rank;
-    c->n_ranks = n_ranks;
-    c->prepared = false;
     return UTM_OK;
 }
 
@@ -350,43 +292,6 @@ extern "C" int utm_p2p_selftest(utm_ctx *c, int32_t *ok)
     return UTM_OK;
 }
 
-// Record mailboxes in HOST memory shared by the shards' processes (a POSIX shared-memory mapping the caller made):
-// the fallback when the device-memory mailboxes cannot be exported or do not pass the self-test.  Every GPU posts
-// and polls over PCIe instead of xGMI -- a few microseconds per exchange, still far below a collective's launch.
-// `shared` must be zero-filled, the same region in every shard, at least utm_p2p_host_mailbox_bytes(n_ranks) long.
-extern "C" int utm_p2p_host_mailbox_bytes(int32_t n_ranks, uint64_t *n_bytes)
-{
-    if (!n_bytes || n_ranks < 1 || n_ranks > UTM_MAX_RANKS) return fail(UTM_EINVAL, "bad arguments");
-    *n_bytes = (uint64_t)n_ranks * 2 * n_ranks * sizeof(Mailbox);
-    return UTM_OK;
-}
-
-extern "C" int utm_p2p_host_mailboxes(utm_ctx *c, void *shared, uint64_t n_bytes)
-{
-    CTX(c);
-    if (!c->p2p) return fail(UTM_ESTATE, "map the shards' columns first (utm_p2p_import)");
-    const u64 per_rank = (u64)2 * c->n_ranks;  // slots [seq & 1][source] of one shard
-    if (!shared || n_bytes < (u64)c->n_ranks * per_rank * sizeof(Mailbox)) return fail(UTM_EINVAL, "shared region too small");
-    if (c->mbox_host) {
-        (void)hipHostUnregister(c->mbox_host);
-        c->mbox_host = nullptr;
-    }
-    HIP_TRY(hipHostRegister(shared, n_bytes, hipHostRegisterMapped | hipHostRegisterPortable));
-    c->mbox_host = shared;
-    void *dev = nullptr;
-    HIP_TRY(hipHostGetDevicePointer(&dev, shared, 0));
-    std::vector<Mailbox *> boxes(c->n_ranks);
-    for (int r = 0; r < c->n_ranks; ++r) boxes[r] = static_cast<Mailbox *>(dev) + (u64)r * per_rank;
-    (void)hipFree(c->d_peer_mbox);
-    c->d_peer_mbox = nullptr;
-    HIP_TRY(hipMalloc(&c->d_peer_mbox, (size_t)c->n_ranks * sizeof(Mailbox *)));
-    HIP_TRY(copy_sync(c, c->d_peer_mbox, boxes.data(), (size_t)c->n_ranks * sizeof(Mailbox *), hipMemcpyHostToDevice));
-    c->mbox_local = boxes[c->rank];
-    c->mbox_ok = false;  // self-test and agree again before use
-    c->prepared = false;
-    return UTM_OK;
-}
-
 extern "C" int utm_p2p_use_mailboxes(utm_ctx *c, int32_t on)
 {
     CTX(c);
@@ -412,51 +317,46 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
 {
     CTX(c);
     if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(UTM_EINVAL, "bad rank %d of %d", rank, n_ranks);
+    if (n_ranks > UTM_MAX_RANKS) return fail(UTM_EINVAL, "at most %d shards", UTM_MAX_RANKS);
     if (c->comm) return fail(UTM_ESTATE, "communicator already initialised");
-    if (c->chunks.empty()) return fail(UTM_ESTATE, "add the chunks before utm_comm_init (the exchange buffer is sized from them)");
+    if (c->chunks.empty()) return fail(UTM_ESTATE, "add the chunks before utm_comm_init (the winner-column buffer is sized from them)");
+    if (c->p2p && (c->rank != rank || c->n_ranks != n_ranks))
+        return fail(UTM_EINVAL, "P2P mappings were imported as rank %d of %d", c->rank, c->n_ranks);
     TRY(rccl_load());
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    NCCL_TRY(g_rccl.CommInitRank(&c->comm, n_ranks, u, rank));
-    if (c->p2p && (c->rank != rank || c->n_ranks != n_ranks))
-        return fail(UTM_EINVAL, "P2P mappings were imported as rank %d of %d", c->rank, c->n_ranks);
-    c->rank = rank;
-    c->n_ranks = n_ranks;
-    // true only if `mine` is true on every rank (collective)
-    auto everywhere = [&](bool mine, bool *all) -> int {
-        double bad = mine ? 0.0 : 1.0;
-        TRY(utm_comm_allreduce_max(c, &bad));
-        *all = bad < 0.5;
-        return UTM_OK;
-    };
-    // Unless the caller already did it (utm_p2p_import), map every rank's columns and record mailboxes (hipIpc):
-    // a winner's column is then read in place over xGMI and the records travel through the mailboxes.  Every step
-    // is agreed on by all ranks; whatever cannot be set up everywhere is left to RCCL.
-    if (n_ranks > 1 && !c->p2p && !tune_env("UTM_NO_P2P", 0)) {
-        uint64_t blob = 0;
-        TRY(utm_p2p_blob_bytes(c, &blob));
-        std::vector<char> mine(blob), all(blob * n_ranks);
-        bool ok = utm_p2p_export(c, mine.data()) == UTM_OK;
-        char *d_all = nullptr;
-        HIP_TRY(hipMalloc(&d_all, blob * n_ranks));
-        HIP_TRY(copy_sync(c, d_all + blob * rank, mine.data(), blob, hipMemcpyHostToDevice));
-        NCCL_TRY(g_rccl.AllGather(d_all + blob * rank, d_all, blob, ncclChar, c->comm, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        HIP_TRY(copy_sync(c, all.data(), d_all, blob * n_ranks, hipMemcpyDeviceToHost));
-        (void)hipFree(d_all);
-        if (ok) ok = utm_p2p_import(c, rank, n_ranks, all.data()) == UTM_OK;
-        bool mapped = false;
-        TRY(everywhere(ok, &mapped));
-        if (!mapped && c->p2p) p2p_close(c);
-        if (mapped && !tune_env("UTM_NO_MAILBOX", 0)) {
-            int32_t box_ok = 0;
-            TRY(utm_p2p_selftest(c, &box_ok));  // can this rank see every peer's mailbox stores?
-            bool boxes = false;
-            TRY(everywhere(box_ok != 0, &boxes));
-            if (boxes) TRY(utm_p2p_use_mailboxes(c, 1));
+    {
+        ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, u, rank);
+        if (r != ncclSuccess) {
+            c->comm = nullptr;
+            return fail(UTM_ECOMM, "ncclCommInitRank(rank %d of %d) -> %s", rank, n_ranks, g_rccl.GetErrorString(r));
         }
     }
-    TRY(ensure_xbuf(c, n_ranks));  // c->comm is set: slots carry whole columns unless P2P is on
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    c->exported = true;  // the peers' covered replicas follow these columns: they must not change any more
+    // every shard's sample range (who owns a global index: the root of a column broadcast)
+    unsigned *d_ranges = nullptr;
+    HIP_TRY(hipMalloc(&d_ranges, (size_t)n_ranks * 8));
+    const unsigned mine[2] = {c->first, c->n_local};
+    hipError_t e = copy_sync(c, d_ranges + 2 * rank, mine, 8, hipMemcpyHostToDevice);
+    ncclResult_t r = e == hipSuccess ? g_rccl.AllGather(d_ranges + 2 * rank, d_ranges, 2, ncclUint32, c->comm, c->stream) : ncclSuccess;
+    std::vector<unsigned> all(2 * (size_t)n_ranks);
+    if (e == hipSuccess && r == ncclSuccess) e = copy_sync(c, all.data(), d_ranges, (size_t)n_ranks * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_ranges);
+    if (r != ncclSuccess) return fail(UTM_ECOMM, "ncclAllGather(sample ranges) -> %s", g_rccl.GetErrorString(r));
+    if (e != hipSuccess) return fail(UTM_EHIP, "exchanging the sample ranges: %s", hipGetErrorString(e));
+    c->rank_first.assign(n_ranks, 0);
+    c->rank_local.assign(n_ranks, 0);
+    u64 covered_samples = 0;
+    for (int k = 0; k < n_ranks; ++k) {
+        c->rank_first[k] = all[2 * k];
+        c->rank_local[k] = all[2 * k + 1];
+        covered_samples += all[2 * k + 1];
+    }
+    if (covered_samples != c->n_total) return fail(UTM_EINVAL, "the shards' ranges do not add up to %u samples", c->n_total);
+    TRY(ensure_xbuf(c, n_ranks));
+    TRY(ensure_wincol(c));
     c->prepared = false;
     return UTM_OK;
 }

@@ -58,7 +58,7 @@ __device__ void decide(const PickArgs &a)
         const unsigned n = st->n_active;
         a.act[st->best_pos] = a.act[n - 1];
         st->n_active = n - 1;
-        st->prev_local = (int)loc;
+        st->prev_local = a.remote_winner_test ? -1 : (int)loc;
     } else {
         st->prev_local = -1;
     }
@@ -358,13 +358,23 @@ __global__ __launch_bounds__(64) void k_mbox_ping(Mailbox *mbox, Mailbox *const 
     if (threadIdx.x == 0 && bad) *ok = 0;
 }
 
-// Exchange payload: this shard's best column (all chunks back to back) behind its record.
-__global__ __launch_bounds__(256) void k_pack(u64 *__restrict__ slot_body, const u64 *__restrict__ cols, u64 wp,
-                                              const IterState *__restrict__ st, const unsigned *__restrict__ act)
+// Sum of the selectable samples' counts (AF byte accounting, see IterState::cnt_sum).  One workgroup.
+__global__ __launch_bounds__(1024) void k_count_sum(IterState *st, const unsigned *__restrict__ act, const u64 *__restrict__ cnt, int base)
 {
-    if (st->done || st->n_active == 0) return;
-    const u64 *col = cols + (u64)act[st->best_pos] * wp;
-    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) slot_body[w] = col[w];
+    __shared__ u64 part[16];
+    u64 sum = 0;
+    const unsigned n = st->n_active;
+    for (unsigned i = threadIdx.x; i < n; i += 1024) sum += cnt[act[i]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 total = 0;
+        for (int w = 0; w < 16; ++w) total += part[w];
+        if (base) st->cnt_sum_base = total;
+        else st->cnt_sum = total;
+    }
 }
 
 // Final per-sample scores of the pending iteration (utm_peek_scores): mask, scale, weight.

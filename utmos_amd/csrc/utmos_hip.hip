@@ -74,6 +74,10 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 static Rccl g_rccl;
@@ -92,6 +96,10 @@ static int rccl_load()
     SYM(CommDestroy, "ncclCommDestroy")
     SYM(AllGather, "ncclAllGather")
     SYM(AllReduce, "ncclAllReduce")
+    SYM(Broadcast, "ncclBroadcast")
+    SYM(GroupStart, "ncclGroupStart")
+    SYM(GroupEnd, "ncclGroupEnd")
+    SYM(CommCount, "ncclCommCount")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     g_rccl.h = h;
@@ -117,6 +125,7 @@ struct Chunk {
     unsigned *afx = nullptr;  // device: fixed-point table of the parallel estimate, wp*64 entries (af_fixed())
     int index = 0;
     const u64 **d_peer_cols = nullptr;  // device array [n_ranks]: this chunk's column base on every rank (P2P), or null
+    std::vector<const u64 *> h_peer_cols;  // the same table on the host
     std::vector<void *> ipc_opened;     // mappings to close
     u64 *replica = nullptr;             // the other shards' columns of this chunk, copied once (when there is room)
     u64 *mask = nullptr;           // AF delta scoring: per word, the bits the last winner newly covered
@@ -147,10 +156,12 @@ struct utm_ctx {
     IterState *h_st = nullptr;  // pinned
     i64 *d_res_idx = nullptr, *d_res_new = nullptr;
     double *d_res_score = nullptr;
-    u64 *d_xbuf = nullptr;  // n_ranks slots of slot_words
-    u64 slot_words = UTM_HDR_WORDS;
+    u64 *d_xbuf = nullptr;  // every shard's 64-byte record of the current iteration: xbuf_ranks x UTM_HDR_WORDS
     int xbuf_ranks = 0;
-    u64 xbuf_slot_words = UTM_HDR_WORDS;  // slot size the buffer was allocated for
+    u64 *d_wincol = nullptr;  // a remote winner's whole column (col_words) as the exchange delivered it: the
+                              // ncclBroadcast from its owner, or utm_apply_records' winner_col
+    u64 wincol_words = 0;
+    bool remote_winner_test = false;  // UTM_TEST_REMOTE_WINNER=1 (tests): read a local winner from d_wincol too
     SeqChunk *d_seq = nullptr;
     CandBuf *d_cand = nullptr;
     ChainFast chain_fast{nullptr, 0, nullptr, nullptr};  // device buffers of the chains' fast path
@@ -167,6 +178,7 @@ struct utm_ctx {
     i64 decr_iterations = 0;
     i64 brute_bytes = 0;
     u64 decr_entries_seen = 0, decr_gathers_seen = 0;
+    u64 cnt_sum_prev = 0;        // AF byte accounting: sum of the selectable samples' counts at the last batch boundary
     u64 *d_varcount = nullptr;
     bool varcount_valid = false;
 
@@ -191,6 +203,7 @@ struct utm_ctx {
     // RCCL
     int rank = 0, n_ranks = 1;
     ncclComm_t comm = nullptr;
+    std::vector<unsigned> rank_first, rank_local;  // every shard's sample range (utm_comm_init / utm_p2p_import)
     // P2P: every rank maps every other rank's columns (hipIpc); the winner's column is then read in place
     bool p2p = false;
     bool exported = false;               // peers map (and may have copied) the columns: they must not change any more
@@ -201,8 +214,7 @@ struct utm_ctx {
     Mailbox *d_mbox = nullptr;           // local slots [2][UTM_MAX_RANKS], uncached device memory, exported to the peers
     Mailbox **d_peer_mbox = nullptr;     // device array [n_ranks] of mapped mailbox bases
     std::vector<void *> mbox_opened;
-    Mailbox *mbox_local = nullptr;       // the slots this shard polls: d_mbox, or its part of a host shared-memory region
-    void *mbox_host = nullptr;           // registered host region (utm_p2p_host_mailboxes), unregistered at destroy
+    Mailbox *mbox_local = nullptr;       // the slots this shard polls (= d_mbox once the peers' mailboxes are mapped)
     bool mbox_ok = false;                // every shard passed the mailbox self-test: utm_run exchanges through them
     u64 xseq_host = 0;                   // exchanges completed so far (self-test rounds included)
 
@@ -221,15 +233,20 @@ static inline u64 round_up(u64 x, u64 m) { return (x + m - 1) / m * m; }
 
 // How kernels find the previous winner's column.  With P2P the scoring kernels never fuse the update
 // (every workgroup would pull the remote tile over xGMI): k_apply_pending reads the column once instead.
+// The per-iteration exchange runs through RCCL (records all-gathered, winner column broadcast) rather than through
+// the device mailboxes; a communicator next to working mailboxes is not used by the loop.
+static bool rccl_exchange(const utm_ctx *c) { return c->comm && !(c->n_ranks > 1 && c->mbox_ok); }
+// Remote winners are read in place through the hipIpc mappings (not from a local copy / the broadcast buffer).
+static bool remote_reads(const utm_ctx *c) { return c->p2p && !c->replicated && !rccl_exchange(c); }
+
 static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel)
 {
     Pending p;
-    p.xbuf = c->d_xbuf;
-    p.slot_words = c->xbuf_slot_words;
+    p.wincol = c->d_wincol;
     p.chunk_off = ch.off;
-    p.peer_cols = c->p2p ? (const u64 *const *)ch.d_peer_cols : nullptr;
+    p.peer_cols = (c->p2p && !rccl_exchange(c)) ? (const u64 *const *)ch.d_peer_cols : nullptr;
     p.peer_first = c->d_peer_first;
-    p.fuse = scoring_kernel && (!c->p2p || c->replicated);  // a remote column is read once, by k_apply_pending
+    p.fuse = scoring_kernel && !remote_reads(c);  // a remote column is read once, by k_apply_pending
     return p;
 }
 
@@ -270,6 +287,10 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     HIP_TRY(hipMalloc(&c->d_cnt_keep, (size_t)n_samp_local * 8));
     HIP_TRY(hipMalloc(&c->d_afsum_keep, (size_t)n_samp_local * 8));
     c->decr_enabled = flags & UTM_FLAG_DECREMENTAL;
+    {
+        const char *t = getenv("UTM_TEST_REMOTE_WINNER");
+        c->remote_winner_test = t && *t == '1';
+    }
     c->xbuf_ranks = 1;
     HIP_TRY(hipEventCreate(&c->ev_loop0));
     HIP_TRY(hipEventCreate(&c->ev_loop1));
@@ -284,7 +305,6 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     p2p_close(c);
-    if (c->mbox_host) (void)hipHostUnregister(c->mbox_host);
     (void)hipFree(c->d_mbox);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (auto &ch : c->chunks) {
@@ -303,7 +323,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
-    (void)hipFree(c->d_xbuf); (void)hipFree(c->d_seq); (void)hipFree(c->d_varcount);
+    (void)hipFree(c->d_xbuf); (void)hipFree(c->d_wincol); (void)hipFree(c->d_seq); (void)hipFree(c->d_varcount);
     if (c->h_st) (void)hipHostFree(c->h_st);
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);

@@ -216,34 +216,15 @@ class DeviceMatrix:
         nat.check(nat.lib().utm_p2p_selftest(self._h, ctypes.byref(ok)))
         return bool(ok.value)
 
-    def p2p_replica_from_host(self, rank, firsts, locals_, chunk_arrays):
-        """chunk_arrays[k]: uint64 array (n_samples, >= ceil(n_var_k / 64)) holding EVERY shard's columns of chunk k in
-        host memory; the other shards' columns are uploaded into a local copy (no hipIpc involved)."""
-        n = len(firsts)
-        f = (ctypes.c_uint32 * n)(*[int(x) for x in firsts])
-        loc = (ctypes.c_uint32 * n)(*[int(x) for x in locals_])
-        ptrs = (ctypes.c_void_p * len(chunk_arrays))(*[a.ctypes.data for a in chunk_arrays])
-        strides = (ctypes.c_uint64 * len(chunk_arrays))(*[a.strides[0] // 8 for a in chunk_arrays])
-        nat.check(nat.lib().utm_p2p_replica_from_host(self._h, int(rank), n, f, loc, ptrs, strides))
-        self.p2p = True
-
-    @staticmethod
-    def p2p_host_mailbox_bytes(n_ranks):
-        n = ctypes.c_uint64()
-        nat.check(nat.lib().utm_p2p_host_mailbox_bytes(int(n_ranks), ctypes.byref(n)))
-        return n.value
-
-    def p2p_host_mailboxes(self, shared):
-        """shared: a writable buffer (mmap of a shared-memory file) every shard maps; kept alive with the matrix."""
-        view = (ctypes.c_char * len(shared)).from_buffer(shared)
-        nat.check(nat.lib().utm_p2p_host_mailboxes(self._h, ctypes.addressof(view), len(shared)))
-        self._host_mailboxes = (shared, view)
-        self.host_mailboxes = True
-
     def p2p_use_mailboxes(self, on=True):
         """After every shard's self-test passed: run() becomes collective, records travel through the mailboxes."""
         nat.check(nat.lib().utm_p2p_use_mailboxes(self._h, 1 if on else 0))
-        self.fused = self.fused_mailboxes = bool(on)
+        self.fused_mailboxes = bool(on)
+        self.fused = bool(on) or getattr(self, "has_comm", False)
+
+    def exchange(self):
+        """How run() meets the other shards right now: 'none', 'mailboxes', 'rccl' or 'caller-driven'."""
+        return nat.EXCHANGE_NAMES[self.stats()["exchange"]]
 
     # -- RCCL
     @staticmethod
@@ -253,9 +234,12 @@ class DeviceMatrix:
         return buf.raw
 
     def comm_init(self, rank, n_ranks, unique_id):
+        """One RCCL communicator over the shards.  Unless the mailboxes are switched on, run() then exchanges through
+        it: ncclAllGather of the records, ncclBroadcast of the winner's column from its owner."""
         buf = ctypes.create_string_buffer(bytes(unique_id), nat.UNIQUE_ID_BYTES)
         nat.check(nat.lib().utm_comm_init(self._h, int(rank), int(n_ranks), buf))
         self.fused = True
+        self.has_comm = True
 
     def allreduce_max(self, value):
         v = ctypes.c_double(float(value))
