@@ -325,3 +325,46 @@ def test_bench_default_line_carries_every_single_gpu_config(tmp_path):
     # cfg3's bytes follow what the AF variant actually reads: a delta pass never re-reads the 40 MB AF table
     per_iter = j["also"]["cfg3"]["algo_bytes_per_step"] / 2504
     assert per_iter < 1.5694e9 * 1.012
+
+
+@pytest.mark.parametrize("extra", [[], ["--af"], ["--af", "--lowmem", "STORE"]], ids=["int", "af", "af-store"])
+def test_cli_reads_a_vcf(extra, tmp_path):
+    """f3: `select x.vcf` -- text VCF -> packed rows -> device, against the oracle fed with the same parsed part.
+    (What the reference's scikit-allel would make of half-missing / haploid calls is parity unpinned; the fixture
+    is build-authored: tests/golden/vcf/build_tiny.vcf.)"""
+    from oracle_util import npo
+    from utmos_amd.vcfio import read_vcf
+    vcf = os.path.join(ou.GOLD, "vcf", "build_tiny.vcf")
+    part = read_vcf(vcf)
+    f32 = "--lowmem" in extra
+    expected = npo.select_tsv([{"GT": part["GT"], "AF": part["AF"].reshape(-1), "samples": part["samples"]}], count=-1,
+                              af="--af" in extra, af_dtype="f32" if f32 else "f64")
+    out = str(tmp_path / "o.tsv")
+    argv = [a if a != "STORE" else str(tmp_path / "v.utm") for a in extra]
+    run_cli(["-c", "-1", "-o", out] + argv + [vcf])
+    assert open(out).read() == expected
+    assert expected.count("\n") > 5
+    # and gzip-compressed
+    import gzip
+    import shutil
+    gz = str(tmp_path / "copy.vcf.gz")
+    with open(vcf, "rb") as src, gzip.open(gz, "wb") as dst:
+        shutil.copyfileobj(src, dst)
+    argv = [a if a != "STORE" else str(tmp_path / "v2.utm") for a in extra]
+    run_cli(["-c", "-1", "-o", out] + argv + [gz])
+    assert open(out).read() == expected
+
+
+def test_cli_reads_a_joblib_part(tmp_path):
+    """f1: the `.jl` branch of the ingest (the reference's own container, utmos/convert.py:98) -- the file is written
+    here with joblib.dump from a re-encoded fixture, mixed with an .npz part like the reference's multi-file test
+    mixes .jl and .vcf (utmos_ssshtests.sh:105-121)."""
+    import joblib
+    p0 = ou.load_part("chunk0")
+    jl = str(tmp_path / "chunk0.jl")
+    joblib.dump({"GT": p0["GT"], "AF": p0["AF"].reshape(-1, 1), "samples": p0["samples"].astype("S"), "stats": {}}, jl, compress=5)
+    out = str(tmp_path / "o.tsv")
+    run_cli(["-o", out, jl, os.path.join(ou.GOLD, "chunk2.npz")])
+    assert open(out).read() == ou.golden_text(CASES["select_multi"])
+    run_cli(["-c", "20", "--af", "-o", out, jl, os.path.join(ou.GOLD, "chunk1.npz")])
+    assert open(out).read() == ou.golden_text(CASES["select_af"])

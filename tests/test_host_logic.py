@@ -292,3 +292,26 @@ def test_packed_store_round_trip_and_shard_views(tmp_path):
         w.add_chunk(64, chunks[1][1])
         w.finish(np.zeros(37, dtype=np.int64))
     assert StoreReader(plain).af(0) is None and not StoreReader(plain).has_af
+
+
+def test_text_vcf_reader_on_the_build_authored_fixture(golden_dir):
+    """utmos_amd/vcfio.py: presence = het or hom-alt of a fully called diploid genotype, phased or not, any alt
+    allele; missing, half-missing and haploid calls are not present (parity unpinned, see the module docstring);
+    AF = largest alt-allele frequency over the called alleles (utmos/convert.py:64-77)."""
+    from utmos_amd.vcfio import read_vcf
+    d = read_vcf(os.path.join(golden_dir, "vcf", "build_tiny.vcf"))
+    assert d["samples"].tolist() == [f"P{i:02d}" for i in range(12)] and d["GT"].shape == (40, 2) and d["AF"].shape == (40, 1)
+    bits = np.unpackbits(d["GT"], axis=1, count=12).astype(bool)
+    text = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(golden_dir, "vcf", "build_tiny.vcf")) if not ln.startswith("#")]
+    for row, fields in zip(bits, text):
+        for present, cell in zip(row, fields[9:]):
+            gt = cell.split(":")[0].replace("|", "/").split("/")
+            want = len(gt) == 2 and "." not in gt and (gt[0] != gt[1] or gt[0] != "0")
+            assert present == want, (fields[1], cell)
+    assert not bits[5].any()                                  # carried by nobody: dropped at ingest later
+    assert not bits[9, 3] and not bits[9, 4]                  # ./1 and 1/. : half-missing
+    assert not bits[11, 2]                                    # haploid "1"
+    # multi-allelic row 0 (ALT T,G): max over the alt alleles
+    alleles = [a for cell in text[0][9:] for a in cell.split(":")[0].replace("|", "/").split("/") if a != "."]
+    want = max(alleles.count("1"), alleles.count("2")) / len(alleles)
+    assert d["AF"][0, 0] == want

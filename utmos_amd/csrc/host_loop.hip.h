@@ -468,20 +468,18 @@ extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
     // with AF every sample's exact reference score is wanted, so all of them take the sequential chain
     c->keep_valid = false;  // the pending winner gets applied here: the next iteration must re-score in full
     TRY(enqueue_score(c, /*force_sequential=*/true, false, nullptr, /*by_sample=*/true));
-    i64 *d_counts = nullptr;
-    double *d_scores = nullptr;
-    HIP_TRY(hipMalloc(&d_counts, (size_t)c->n_local * 8));
-    HIP_TRY(hipMalloc(&d_scores, (size_t)c->n_local * 8));
+    Scratch<i64> d_counts;
+    Scratch<double> d_scores;
+    HIP_TRY(d_counts.alloc(c->n_local));
+    HIP_TRY(d_scores.alloc(c->n_local));
     PickArgs pa = pick_args(c);
     pa.afsum = nullptr;
-    hipLaunchKernelGGL(k_final_scores, dim3((c->n_local + 255) / 256), dim3(256), 0, c->stream, pa, d_counts, d_scores);
+    hipLaunchKernelGGL(k_final_scores, dim3((c->n_local + 255) / 256), dim3(256), 0, c->stream, pa, d_counts.p, d_scores.p);
     (void)hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream);
     (void)hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess && counts) e = copy_sync(c, counts, d_counts, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && scores) e = copy_sync(c, scores, d_scores, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d_counts);
-    (void)hipFree(d_scores);
+    if (e == hipSuccess && counts) e = copy_sync(c, counts, d_counts.p, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && scores) e = copy_sync(c, scores, d_scores.p, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(UTM_EHIP, "peek: %s", hipGetErrorString(e));
     return UTM_OK;
 }

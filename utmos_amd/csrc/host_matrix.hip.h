@@ -76,20 +76,19 @@ extern "C" int utm_upload_rows_packed(utm_ctx *c, int32_t chunk, uint64_t first_
     if (row_stride_bytes < ((u64)c->n_total + 7) / 8) return fail(UTM_EINVAL, "row stride shorter than ceil(S/8)");
     // staged in slabs of at most 64 MiB
     const u64 slab_rows = std::max<u64>(64, ((64ull << 20) / row_stride_bytes) / 64 * 64);
-    unsigned char *d_rows = nullptr;
-    HIP_TRY(hipMalloc(&d_rows, std::min(slab_rows, round_up(n_rows, 64)) * row_stride_bytes));
+    Scratch<unsigned char> d_rows;
+    HIP_TRY(d_rows.alloc(std::min(slab_rows, round_up(n_rows, 64)) * row_stride_bytes));
     int rc = UTM_OK;
     for (u64 r0 = 0; r0 < n_rows && rc == UTM_OK; r0 += slab_rows) {
         const u64 nr = std::min(slab_rows, n_rows - r0);
-        hipError_t e = hipMemcpyAsync(d_rows, rows + r0 * row_stride_bytes, nr * row_stride_bytes, hipMemcpyHostToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync(d_rows.p, rows + r0 * row_stride_bytes, nr * row_stride_bytes, hipMemcpyHostToDevice, c->stream);
         if (e != hipSuccess) { rc = fail(UTM_EHIP, "row upload: %s", hipGetErrorString(e)); break; }
         dim3 grid((unsigned)((nr + 63) / 64), (c->n_local + 63) / 64);
-        hipLaunchKernelGGL(k_transpose_rows, grid, dim3(64), 0, c->stream, d_rows, (u64)row_stride_bytes, nr,
+        hipLaunchKernelGGL(k_transpose_rows, grid, dim3(64), 0, c->stream, d_rows.p, (u64)row_stride_bytes, nr,
                            (first_var + r0) / 64, ch->cols, ch->wp, c->first, c->n_local, c->n_total);
         e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) rc = fail(UTM_EHIP, "row transpose: %s", hipGetErrorString(e));
     }
-    (void)hipFree(d_rows);
     ch->rows_t_valid = false;
     c->prepared = false;
     c->varcount_valid = false;

@@ -63,12 +63,11 @@ extern "C" int utm_set_af(utm_ctx *c, int32_t chunk, int mode, const void *af)
         if (c->exported) return fail(UTM_ESTATE, "the columns are exported to other shards (utm_p2p_export): set the AF before exporting");
         TRY(ensure_var_count(c));
         ch->rows_t_valid = false;
-        u64 *d_keep = nullptr;
-        HIP_TRY(hipMalloc(&d_keep, ch->w * 8));
-        HIP_TRY(copy_sync(c, d_keep, keep.data(), ch->w * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_mask_rows, dim3(4096), dim3(256), 0, c->stream, ch->cols, ch->wp, d_keep, ch->w, c->n_local);
+        Scratch<u64> d_keep;
+        HIP_TRY(d_keep.alloc(ch->w));
+        HIP_TRY(copy_sync(c, d_keep.p, keep.data(), ch->w * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_mask_rows, dim3(4096), dim3(256), 0, c->stream, ch->cols, ch->wp, d_keep.p, ch->w, c->n_local);
         hipError_t e = hipStreamSynchronize(c->stream);
-        (void)hipFree(d_keep);
         if (e != hipSuccess) return fail(UTM_EHIP, "mask rows: %s", hipGetErrorString(e));
     }
     ch->h_af32.clear();

@@ -273,19 +273,18 @@ extern "C" int utm_p2p_selftest(utm_ctx *c, int32_t *ok)
     if (!ok) return fail(UTM_EINVAL, "ok is NULL");
     *ok = 0;
     if (!c->p2p || !c->d_peer_mbox) return UTM_OK;  // nothing to test: answer "no"
-    int *d_ok = nullptr;
-    HIP_TRY(hipMalloc(&d_ok, 4));
+    Scratch<int> d_ok;
+    HIP_TRY(d_ok.alloc(1));
     int one = 1;
-    HIP_TRY(copy_sync(c, d_ok, &one, 4, hipMemcpyHostToDevice));
+    HIP_TRY(copy_sync(c, d_ok.p, &one, 4, hipMemcpyHostToDevice));
     for (int round = 0; round < 4; ++round) {
         c->xseq_host += 1;
         hipLaunchKernelGGL(k_mbox_ping, dim3(1), dim3(64), 0, c->stream, c->mbox_local, c->d_peer_mbox, c->rank, c->n_ranks,
-                           c->xseq_host, d_ok);
+                           c->xseq_host, d_ok.p);
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     int got = 0;
-    if (e == hipSuccess) e = copy_sync(c, &got, d_ok, 4, hipMemcpyDeviceToHost);
-    (void)hipFree(d_ok);
+    if (e == hipSuccess) e = copy_sync(c, &got, d_ok.p, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(UTM_EHIP, "mailbox self-test: %s", hipGetErrorString(e));
     *ok = got;
     c->prepared = false;  // the loop state carries the exchange sequence number
@@ -336,16 +335,13 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
     c->n_ranks = n_ranks;
     c->exported = true;  // the peers' covered replicas follow these columns: they must not change any more
     // every shard's sample range (who owns a global index: the root of a column broadcast)
-    unsigned *d_ranges = nullptr;
-    HIP_TRY(hipMalloc(&d_ranges, (size_t)n_ranks * 8));
+    Scratch<unsigned> d_ranges;
+    HIP_TRY(d_ranges.alloc(2 * (size_t)n_ranks));
     const unsigned mine[2] = {c->first, c->n_local};
-    hipError_t e = copy_sync(c, d_ranges + 2 * rank, mine, 8, hipMemcpyHostToDevice);
-    ncclResult_t r = e == hipSuccess ? g_rccl.AllGather(d_ranges + 2 * rank, d_ranges, 2, ncclUint32, c->comm, c->stream) : ncclSuccess;
+    HIP_TRY(copy_sync(c, d_ranges.p + 2 * rank, mine, 8, hipMemcpyHostToDevice));
+    NCCL_TRY(g_rccl.AllGather(d_ranges.p + 2 * rank, d_ranges.p, 2, ncclUint32, c->comm, c->stream));
     std::vector<unsigned> all(2 * (size_t)n_ranks);
-    if (e == hipSuccess && r == ncclSuccess) e = copy_sync(c, all.data(), d_ranges, (size_t)n_ranks * 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d_ranges);
-    if (r != ncclSuccess) return fail(UTM_ECOMM, "ncclAllGather(sample ranges) -> %s", g_rccl.GetErrorString(r));
-    if (e != hipSuccess) return fail(UTM_EHIP, "exchanging the sample ranges: %s", hipGetErrorString(e));
+    HIP_TRY(copy_sync(c, all.data(), d_ranges.p, (size_t)n_ranks * 8, hipMemcpyDeviceToHost));
     c->rank_first.assign(n_ranks, 0);
     c->rank_local.assign(n_ranks, 0);
     u64 covered_samples = 0;
@@ -366,14 +362,10 @@ extern "C" int utm_comm_allreduce_max(utm_ctx *c, double *value)
     CTX(c);
     if (!value) return fail(UTM_EINVAL, "value is NULL");
     if (!c->comm) return UTM_OK;  // single shard: identity
-    double *d = nullptr;
-    HIP_TRY(hipMalloc(&d, 8));
-    HIP_TRY(hipMemcpyAsync(d, value, 8, hipMemcpyHostToDevice, c->stream));
-    ncclResult_t r = g_rccl.AllReduce(d, d, 1, ncclDouble, ncclMax, c->comm, c->stream);
-    hipError_t e = hipMemcpyAsync(value, d, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(d);
-    if (r != ncclSuccess) return fail(UTM_ECOMM, "ncclAllReduce -> %s", g_rccl.GetErrorString(r));
-    if (e != hipSuccess) return fail(UTM_EHIP, "allreduce copy: %s", hipGetErrorString(e));
+    Scratch<double> d;
+    HIP_TRY(d.alloc(1));
+    HIP_TRY(hipMemcpyAsync(d.p, value, 8, hipMemcpyHostToDevice, c->stream));
+    NCCL_TRY(g_rccl.AllReduce(d.p, d.p, 1, ncclDouble, ncclMax, c->comm, c->stream));
+    HIP_TRY(copy_sync(c, value, d.p, 8, hipMemcpyDeviceToHost));
     return UTM_OK;
 }

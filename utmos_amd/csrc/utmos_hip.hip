@@ -341,6 +341,18 @@ static hipError_t copy_sync(utm_ctx *c, void *dst, const void *src, size_t bytes
     return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
 }
 
+// A device allocation that lives for one call: released on every way out, error returns included.
+template <typename T>
+struct Scratch {
+    T *p = nullptr;
+    Scratch() = default;
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    ~Scratch() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(&p, count * sizeof(T)); }
+    operator T *() const { return p; }
+};
+
 #define CTX(c)                                        \
     if (!(c)) return fail(UTM_EINVAL, "ctx is NULL"); \
     HIP_TRY(hipSetDevice((c)->device))

@@ -3,7 +3,12 @@
 The reference reads VCFs through scikit-allel (utmos/convert.py:43-88), a third-party library that
 is not part of the reference tree: presence = het or hom-alt call, AF = max alt-allele frequency over
 called alleles.  This reader reproduces that for fully called diploid genotypes (its GT bytes equal
-the reference's chunk0/chunk1 fixtures); half-missing and haploid calls are *parity unpinned*.
+the reference's chunk0/chunk1 fixtures).  A haploid call ("1", chrX/chrY males) is NOT counted as present:
+scikit-allel pads it to a diploid call with a missing second allele, which is neither het nor hom-alt.
+Half-missing and haploid calls are *parity unpinned*: no fixture of the reference holds one.  So is AF on
+multi-allelic rows: this reader follows utmos/convert.py:75-77 (largest alt-allele frequency), while the
+reference's own chunk0.jl / chunk1.jl fixtures carry the FIRST alt allele's frequency on their five multi-allelic
+rows (an older convert, presumably) -- and no golden of the reference scores a VCF input with --af.
 """
 import gzip
 
@@ -32,11 +37,11 @@ def read_vcf(path):
                 for a in al:
                     if 0 <= a <= n_alt:
                         counts[a] += 1
-                called = all(a >= 0 for a in al)
-                if called and len(al) > 1 and any(a != al[0] for a in al[1:]):
-                    pres[j] = True
-                elif called and al[0] > 0 and all(a == al[0] for a in al):
-                    pres[j] = True
+                called = len(al) > 1 and all(a >= 0 for a in al)      # (haploid = padded with a missing allele: not called)
+                if called and any(a != al[0] for a in al[1:]):
+                    pres[j] = True                                      # het
+                elif called and al[0] > 0:
+                    pres[j] = True                                      # hom-alt
             total = counts.sum()
             afs.append((counts[1:] / total).max() if total and n_alt else 0.0)
             rows.append(pres)
