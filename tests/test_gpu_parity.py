@@ -816,3 +816,40 @@ def test_af_estimate_scores_mode_keeps_the_rows(dev, kind):
         idx, new, score = m.run(n_samp)
     assert idx.tolist() == exp[0].tolist() and new.tolist() == exp[1].tolist()
     assert np.allclose(score, exp[2], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "tiny_mixed", "f32_grid", "coarse_grid", "long"])
+def test_parallel_chain_reproduces_sequential_float64_sums(dev, kind):
+    """k_chain's parallel form (parity-state scan, af_verify.hip.h) against plain sequential float64 addition in
+    ascending variant order -- the reference's `scores += row` (select.py:40) -- on value patterns that stress it:
+    full 53-bit mantissas, values far below the sum's last bit, float32 grids where every other addend is an exact
+    tie, and sums that cross many binades."""
+    rng = np.random.default_rng({"uniform": 1, "tiny_mixed": 2, "f32_grid": 3, "coarse_grid": 4, "long": 5}[kind])
+    for trial in range(6 if kind == "long" else 40):
+        # (short lists too: a sum crosses a binade every few addends at the start, and the addend that crosses is
+        # where a window ends -- once a source of error, when the sum in front of it was taken from an inexact total)
+        n_var = (int(rng.integers(200, 9000)) if trial % 2 else int(rng.integers(2, 80))) if kind != "long" else 600_000
+        if kind in ("uniform", "long"):
+            af = rng.random(n_var)
+        elif kind == "tiny_mixed":
+            af = rng.random(n_var) * 1e-3
+            af[rng.random(n_var) < 0.3] *= 1e-25
+        elif kind == "f32_grid":
+            af = rng.random(n_var).astype(np.float32).astype(np.float64)
+        else:
+            af = rng.integers(1, 2 ** 24, n_var) * 2.0 ** -30
+        af = np.maximum(af, 1e-300)
+        dense = np.zeros((n_var, 3), dtype=bool)
+        dense[:, 0] = rng.random(n_var) < (0.9 if kind != "long" else 0.97)
+        dense[:, 1] = rng.random(n_var) < 0.2
+        dense[~dense.any(axis=1), 2] = True
+        want = 0.0
+        for a in af[dense[:, 0]]:
+            want = want + float(a)
+        with dev.DeviceMatrix(3) as m:
+            c = m.add_chunk(n_var)
+            m.upload_columns(c, npo.pack_columns(dense))
+            m.set_af(c, af)
+            got = m.step()
+        assert got is not None and got[0] == 0, (kind, trial)
+        assert float(got[2]).hex() == float(want).hex(), (kind, trial, n_var)

@@ -125,6 +125,7 @@ __device__ __forceinline__ double ordered_sum64(double acc, double v)
 #define UTM_FAST_CAND 8
 #define UTM_SEG_CAP 1024
 #define UTM_SEG_WORDS 4096
+#define UTM_SEG_FULL (UTM_SEG_WORDS * 64)  // every bit of a segment set
 struct ChainSeg {
     int chunk;
     u64 w0;
@@ -132,8 +133,10 @@ struct ChainSeg {
 struct ChainFast {
     const ChainSeg *segs;
     int n_segs;
-    unsigned *counts;  // [UTM_FAST_CAND][n_segs]; 0xFFFFFFFF = segment too dense
-    double *vals;      // [UTM_FAST_CAND][n_segs][UTM_SEG_CAP]
+    unsigned *counts;  // [n_cand][n_segs]; 0xFFFFFFFF = more values than seg_cap in that segment
+    double *vals;      // [n_cand][n_segs][seg_cap]
+    unsigned seg_cap;  // values a segment's region holds: UTM_SEG_FULL (every segment fits) when the memory allows, else UTM_SEG_CAP
+    int n_cand;        // candidates with buffers (<= UTM_FAST_CAND)
 };
 
 template <typename AF_T>
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict_
                                                      const CandBuf *__restrict__ cand, ChainFast f)
 {
     __shared__ unsigned wtot[16];
-    if (st->done || !st->need_chain || st->cand_overflow || st->n_cand > UTM_FAST_CAND || (int)blockIdx.y >= st->n_cand) return;
+    if (st->done || !st->need_chain || st->cand_overflow || st->n_cand > f.n_cand || (int)blockIdx.y >= st->n_cand) return;
     const ChainSeg sg = f.segs[blockIdx.x];
     const SeqChunk ch = chunks[sg.chunk];
     const unsigned s = cand->samp[blockIdx.y];
@@ -167,9 +170,9 @@ __global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict_
         total += t;
     }
     const size_t slot = (size_t)blockIdx.y * f.n_segs + blockIdx.x;
-    if (tid == 0) f.counts[slot] = total <= UTM_SEG_CAP ? total : 0xFFFFFFFFu;
-    if (total == 0 || total > UTM_SEG_CAP) return;
-    double *out = f.vals + slot * UTM_SEG_CAP + (woff + incl - n);
+    if (tid == 0) f.counts[slot] = total <= f.seg_cap ? total : 0xFFFFFFFFu;
+    if (total == 0 || total > f.seg_cap) return;
+    double *out = f.vals + slot * f.seg_cap + (woff + incl - n);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         u64 y = x[k];
@@ -179,6 +182,166 @@ __global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict_
             *out++ = (double)af[(w + k) * 64 + b];
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// The reference's chain, in parallel and still bit for bit.  acc_{i+1} = RN(acc_i + a_i) in float64, round to
+// nearest even, ascending variant order (select.py:40), all a_i >= 0.  While the running sum stays inside one
+// binade [2^e, 2^(e+1)) it is an integer M in [2^52, 2^53) times the unit U = 2^(e-52), and adding a_i adds the
+// INTEGER q_i = a_i / U rounded to nearest -- which depends on a_i alone -- except for exact ties
+// (a_i / U = k + 1/2), which go to whichever of k, k + 1 makes M even: they depend on the parity of M, and leave it
+// even.  So the parity of M is a two-state machine driven by the addends (a tie resets it, anything else XORs it
+// with q_i's low bit), its state in front of every addend comes out of a prefix scan over 2-bit maps, every q_i
+// follows, and a second prefix scan (of the q_i) says where M would reach 2^53.  Up to there the window is
+// finished in one go: acc = (M + sum q) * U, exactly the value the sequential additions produce.  The addend that
+// crosses into the next binade is added with one real float64 addition, and the scan restarts behind it with the
+// new unit.  1024 threads x 4 addends per round; a sum crosses ~log2(n) binades, so rounds ~ n / 4096 + log2(n)
+// instead of n dependent additions.  Integer-valued doubles below 2^53 carry M, q and their partial sums exactly;
+// a partial sum that reaches 2^53 may round, but never back below 2^53, which is all the crossing test needs.
+// ------------------------------------------------------------------------------------------------
+#define UTM_PAR_E 4
+#define UTM_PAR_MAX_SEGS 4095
+__device__ __forceinline__ unsigned pm_then(unsigned first, unsigned second)  // maps on {0,1}: bit p = image of p
+{
+    return ((second >> (first & 1)) & 1) | (((second >> ((first >> 1) & 1)) & 1) << 1);
+}
+__device__ __forceinline__ int low_bit(double integer_valued) { return (int)(integer_valued - 2.0 * floor(0.5 * integer_valued)); }
+
+struct ParScratch {       // LDS
+    unsigned wmap[16];
+    double wsum[16];
+    unsigned wcross[16];
+    double crossed;       // the running sum right after the crossing addend
+};
+
+// vals: this candidate's compacted addends, segment g's at vals + g * seg_cap; offs (LDS): exclusive prefix of the
+// segments' counts, n_segs + 1 entries.  Every thread of the 1024 calls this; every thread returns the sum.
+__device__ __forceinline__ double chain_parallel(const double *__restrict__ vals, size_t seg_cap, const unsigned *offs, int n_segs,
+                                                 ParScratch &sc)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned total = offs[n_segs];
+    auto value_at = [&](unsigned g, int &seg) -> double {  // seg: a segment at or before g's, advanced to g's
+        while (g >= offs[seg + 1]) ++seg;
+        return vals[(size_t)seg * seg_cap + (g - offs[seg])];
+    };
+    double acc = 0.0;
+    unsigned pos = 0;
+    while (pos < total) {
+        if (acc == 0.0) {  // 0 + a = a
+            int seg = 0;
+            acc = value_at(pos, seg);
+            ++pos;
+            continue;
+        }
+        const int e = (int)((__builtin_bit_cast(u64, acc) >> 52) & 0x7FF) - 1023;
+        const int scale = 52 - e;
+        const double m0 = ldexp(acc, scale);                 // M: integer in [2^52, 2^53)
+        const double limit = 9007199254740992.0 - m0;        // the sum of q reaching this = leaving the binade
+        const unsigned g0 = pos + (unsigned)tid * UTM_PAR_E;
+        double a[UTM_PAR_E], k[UTM_PAR_E];
+        int tie[UTM_PAR_E];
+        {
+            int seg = 0;
+            if (g0 < total) {  // binary search: last segment whose offset is <= g0
+                int lo = 0, hi = n_segs - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (offs[mid] <= g0) lo = mid;
+                    else hi = mid - 1;
+                }
+                seg = lo;
+            }
+#pragma unroll
+            for (int j = 0; j < UTM_PAR_E; ++j) a[j] = g0 + j < total ? value_at(g0 + j, seg) : 0.0;
+        }
+        unsigned map = 2u;  // identity
+#pragma unroll
+        for (int j = 0; j < UTM_PAR_E; ++j) {
+            const double x = ldexp(a[j], scale);             // a / U, exact (a power-of-two scaling)
+            const double fl = floor(x);
+            const double r = x - fl;                         // exact
+            tie[j] = r == 0.5;
+            k[j] = fl + (r > 0.5 ? 1.0 : 0.0);               // q unless a tie; a tie: k or k + 1
+            map = pm_then(map, tie[j] ? 0u : (low_bit(k[j]) ? 1u : 2u));
+        }
+        unsigned inc = map;  // inclusive scan of the maps over the wave, then over the waves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned other = __shfl_up(inc, o, 64);
+            if (lane >= o) inc = pm_then(other, inc);
+        }
+        if (lane == 63) sc.wmap[wave] = inc;
+        __syncthreads();
+        unsigned before = 2u;
+        for (int w = 0; w < wave; ++w) before = pm_then(before, sc.wmap[w]);
+        unsigned excl = __shfl_up(inc, 1, 64);
+        if (lane == 0) excl = 2u;
+        int par = (pm_then(before, excl) >> low_bit(m0)) & 1;  // parity of M in front of this thread's first addend
+        double q[UTM_PAR_E], mine = 0.0;
+#pragma unroll
+        for (int j = 0; j < UTM_PAR_E; ++j) {
+            if (tie[j]) {
+                q[j] = k[j] + (double)((par + low_bit(k[j])) & 1);  // ... to the even neighbour
+                par = 0;
+            } else {
+                q[j] = k[j];
+                par ^= low_bit(k[j]);
+            }
+            mine += q[j];
+        }
+        double incs = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double other = __shfl_up(incs, o, 64);
+            if (lane >= o) incs += other;
+        }
+        if (lane == 63) sc.wsum[wave] = incs;
+        __syncthreads();
+        double in_front = 0.0, all = 0.0;
+        for (int w = 0; w < 16; ++w) {
+            const double t = sc.wsum[w];
+            in_front += w < wave ? t : 0.0;
+            all += t;
+        }
+        if (all < limit) {  // the whole window stays in the binade (uniform: every thread sees the same total)
+            acc = ldexp(m0 + all, -scale);
+            pos = total - pos > 1024u * UTM_PAR_E ? pos + 1024u * UTM_PAR_E : total;
+            continue;
+        }
+        // the first addend whose q takes M to 2^53 or beyond is added for real.  (The sum in front of this thread's
+        // addends comes from the previous lane's inclusive value, never from `incs - mine`: sums past 2^53 are no longer
+        // exact, and this thread's own addends may be what takes them there.)
+        double lanes_before = __shfl_up(incs, 1, 64);
+        if (lane == 0) lanes_before = 0.0;
+        double run = in_front + lanes_before, at = 0.0, addend = 0.0;
+        unsigned first = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < UTM_PAR_E; ++j) {
+            if (first == 0xFFFFFFFFu && run + q[j] >= limit) {
+                first = g0 + j;
+                at = run;
+                addend = a[j];
+            }
+            run += q[j];
+        }
+        unsigned wmin = first;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned other = __shfl_xor(wmin, o, 64);
+            wmin = other < wmin ? other : wmin;
+        }
+        if (lane == 0) sc.wcross[wave] = wmin;
+        __syncthreads();
+        unsigned where = 0xFFFFFFFFu;
+        for (int w = 0; w < 16; ++w) where = sc.wcross[w] < where ? sc.wcross[w] : where;
+        if (first == where) sc.crossed = ldexp(m0 + at, -scale) + addend;  // (exactly one thread owns that addend)
+        __syncthreads();
+        acc = sc.crossed;
+        pos = where + 1;
+    }
+    return acc;
 }
 
 #define UTM_CHAIN_CAP 2048
@@ -193,27 +356,41 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
     if (st->done || !st->need_chain || st->cand_overflow || (int)blockIdx.x >= st->n_cand) return;
     const unsigned s = cand->samp[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (f.counts && st->n_cand <= UTM_FAST_CAND) {
-        // fast path: k_chain_fill compacted this candidate's values per segment; are all segments usable?
+    if (f.counts && st->n_cand <= f.n_cand && f.n_segs <= UTM_PAR_MAX_SEGS) {
+        // k_chain_fill compacted this candidate's addends per segment: if every segment fitted its region, all 1024
+        // threads run the parallel form of the chain over them
+        __shared__ ParScratch sc;
         const unsigned *cnts = f.counts + (size_t)blockIdx.x * f.n_segs;
+        unsigned *offs = reinterpret_cast<unsigned *>(buf);  // n_segs + 1 <= 4096 entries
         if (tid == 0) dense = 0;
         __syncthreads();
-        for (int g = tid; g < f.n_segs; g += 1024)
-            if (cnts[g] == 0xFFFFFFFFu) dense = 1;
+        // exclusive prefix of the segment counts: 4 consecutive segments per thread
+        unsigned c4[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = tid * 4 + j;
+            c4[j] = g < f.n_segs ? cnts[g] : 0u;
+            if (c4[j] == 0xFFFFFFFFu) dense = 1;
+            mine += c4[j];
+        }
+        const unsigned incl = wave_scan_incl_u32(mine);
+        if (lane == 63) wtot[0][wave] = incl;
         __syncthreads();
         if (!dense) {
-            if (wave == 0) {  // one wave: coalesced loads of 64 values, then the ordered sum in registers
-                double acc = 0.0;
-                const double *vals = f.vals + (size_t)blockIdx.x * f.n_segs * UTM_SEG_CAP;
-                for (int g = 0; g < f.n_segs; ++g) {
-                    const unsigned m = cnts[g];
-                    const double *v = vals + (size_t)g * UTM_SEG_CAP;
-                    for (unsigned t = 0; t < m; t += 64) acc = ordered_sum64(acc, t + lane < m ? v[t + lane] : 0.0);
-                }
-                if (lane == 0) cand->val[blockIdx.x] = acc;
+            unsigned off = incl - mine;
+            for (int w = 0; w < wave; ++w) off += wtot[0][w];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = tid * 4 + j;
+                if (g <= f.n_segs) offs[g] = off;  // (g == n_segs: the total)
+                off += c4[j];
             }
+            __syncthreads();
+            const double sum = chain_parallel(f.vals + (size_t)blockIdx.x * f.n_segs * f.seg_cap, f.seg_cap, offs, f.n_segs, sc);
+            if (tid == 0) cand->val[blockIdx.x] = sum;
             return;
         }
+        __syncthreads();  // (dense: the one-workgroup chain below reuses buf)
     }
     double acc = 0.0;
     unsigned round = 0;

@@ -264,13 +264,13 @@ static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
     const ChainFast &cf = c->chain_fast;
     if (c->af_mode == UTM_AF_F32) {
         if (cf.counts)
-            hipLaunchKernelGGL(k_chain_fill<float>, dim3(cf.n_segs, UTM_FAST_CAND), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
+            hipLaunchKernelGGL(k_chain_fill<float>, dim3(cf.n_segs, cf.n_cand), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
         hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand, cf);
         hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
                            c->d_act, c->d_cnt, c->d_fscore, 1);
     } else {
         if (cf.counts)
-            hipLaunchKernelGGL(k_chain_fill<double>, dim3(cf.n_segs, UTM_FAST_CAND), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
+            hipLaunchKernelGGL(k_chain_fill<double>, dim3(cf.n_segs, cf.n_cand), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
         hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand, cf);
         hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
                            c->d_act, c->d_cnt, c->d_fscore, 1);

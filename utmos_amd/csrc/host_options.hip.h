@@ -182,7 +182,7 @@ static int build_af_tables(utm_ctx *c)
     // segment table + buffers of the chains' fast path
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     c->d_segs = nullptr;
-    c->chain_fast = ChainFast{nullptr, 0, nullptr, nullptr};
+    c->chain_fast = ChainFast{nullptr, 0, nullptr, nullptr, 0, 0};
     if (c->af_fixed)
         for (auto &ch : c->chunks)
             if (!ch.mask) HIP_TRY(hipMalloc(&ch.mask, ch.wp * 8));
@@ -191,13 +191,26 @@ static int build_af_tables(utm_ctx *c)
         for (size_t k = 0; k < c->chunks.size(); ++k)
             for (u64 w0 = 0; w0 < c->chunks[k].w; w0 += UTM_SEG_WORDS) segs.push_back(ChainSeg{(int)k, w0});
         const size_t n = segs.size();
-        if (n * UTM_FAST_CAND * UTM_SEG_CAP * 8 <= (4ull << 30)) {  // keep the scratch within 4 GiB
+        // regions for the candidates' compacted addends: room for EVERY bit of a segment where the memory allows
+        // (all candidates, then two), so that the parallel chain always applies; else 1024 values per segment and
+        // denser segments leave their candidate to the one-workgroup chain
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t budget = std::min<size_t>(free_b / 4, 16ull << 30);
+        unsigned cap = 0;
+        int n_cand = 0;
+        if (n * UTM_FAST_CAND * (size_t)UTM_SEG_FULL * 8 <= budget) { cap = UTM_SEG_FULL; n_cand = UTM_FAST_CAND; }
+        else if (n * 2 * (size_t)UTM_SEG_FULL * 8 <= budget) { cap = UTM_SEG_FULL; n_cand = 2; }
+        else if (n * UTM_FAST_CAND * (size_t)UTM_SEG_CAP * 8 <= (4ull << 30)) { cap = UTM_SEG_CAP; n_cand = UTM_FAST_CAND; }
+        if (cap) {
             HIP_TRY(hipMalloc(&c->d_segs, n * sizeof(ChainSeg)));
             HIP_TRY(copy_sync(c, c->d_segs, segs.data(), n * sizeof(ChainSeg), hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc(&c->chain_fast.counts, n * UTM_FAST_CAND * 4));
-            HIP_TRY(hipMalloc(&c->chain_fast.vals, n * UTM_FAST_CAND * UTM_SEG_CAP * 8));
+            HIP_TRY(hipMalloc(&c->chain_fast.counts, n * n_cand * 4));
+            HIP_TRY(hipMalloc(&c->chain_fast.vals, n * n_cand * (size_t)cap * 8));
             c->chain_fast.segs = c->d_segs;
             c->chain_fast.n_segs = (int)n;
+            c->chain_fast.seg_cap = cap;
+            c->chain_fast.n_cand = n_cand;
         }
     }
     c->dirty_tables = false;

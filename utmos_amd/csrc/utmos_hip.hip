@@ -164,7 +164,7 @@ struct utm_ctx {
     bool remote_winner_test = false;  // UTM_TEST_REMOTE_WINNER=1 (tests): read a local winner from d_wincol too
     SeqChunk *d_seq = nullptr;
     CandBuf *d_cand = nullptr;
-    ChainFast chain_fast{nullptr, 0, nullptr, nullptr};  // device buffers of the chains' fast path
+    ChainFast chain_fast{nullptr, 0, nullptr, nullptr, 0, 0};  // device buffers of the chains' fast path
     ChainSeg *d_segs = nullptr;
     u64 *d_cnt_keep = nullptr;   // persistent per-sample counts (mirror of the last full scoring, then decremented)
     i64 *d_afsum_keep = nullptr;
