@@ -201,12 +201,52 @@ __global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict_
 // a partial sum that reaches 2^53 may round, but never back below 2^53, which is all the crossing test needs.
 // ------------------------------------------------------------------------------------------------
 #define UTM_PAR_E 4
+#define UTM_PAR_HEAD 256
 #define UTM_PAR_MAX_SEGS 4095
 __device__ __forceinline__ unsigned pm_then(unsigned first, unsigned second)  // maps on {0,1}: bit p = image of p
 {
     return ((second >> (first & 1)) & 1) | (((second >> ((first >> 1) & 1)) & 1) << 1);
 }
 __device__ __forceinline__ int low_bit(double integer_valued) { return (int)(integer_valued - 2.0 * floor(0.5 * integer_valued)); }
+
+// Inclusive wave scans on the DPP ladder of wave_scan_incl_u32 (row shifts, then row broadcasts): a lane without a
+// source keeps the operator's identity, and the earlier lanes' value is always the first operand, so the ladder
+// also serves the (associative, non-commutative) composition of parity maps.
+#define UTM_DPP_U32(old, v, ctrl, rmask) (unsigned)__builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, rmask, 0xf, false)
+__device__ __forceinline__ unsigned wave_scan_maps(unsigned m)
+{
+    m = pm_then(UTM_DPP_U32(2u, m, 0x111, 0xf), m);  // row_shr:1
+    m = pm_then(UTM_DPP_U32(2u, m, 0x112, 0xf), m);  // row_shr:2
+    m = pm_then(UTM_DPP_U32(2u, m, 0x114, 0xf), m);  // row_shr:4
+    m = pm_then(UTM_DPP_U32(2u, m, 0x118, 0xf), m);  // row_shr:8
+    m = pm_then(UTM_DPP_U32(2u, m, 0x142, 0xa), m);  // row_bcast:15 -> rows 1, 3
+    m = pm_then(UTM_DPP_U32(2u, m, 0x143, 0xc), m);  // row_bcast:31 -> rows 2, 3
+    return m;
+}
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl, const int rmask)
+{
+    const u64 b = __builtin_bit_cast(u64, v);
+    unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    switch (ctrl) {  // (the control word must be a compile-time constant)
+    case 0x111: lo = UTM_DPP_U32(0u, lo, 0x111, 0xf); hi = UTM_DPP_U32(0u, hi, 0x111, 0xf); break;
+    case 0x112: lo = UTM_DPP_U32(0u, lo, 0x112, 0xf); hi = UTM_DPP_U32(0u, hi, 0x112, 0xf); break;
+    case 0x114: lo = UTM_DPP_U32(0u, lo, 0x114, 0xf); hi = UTM_DPP_U32(0u, hi, 0x114, 0xf); break;
+    case 0x118: lo = UTM_DPP_U32(0u, lo, 0x118, 0xf); hi = UTM_DPP_U32(0u, hi, 0x118, 0xf); break;
+    case 0x142: lo = UTM_DPP_U32(0u, lo, 0x142, 0xa); hi = UTM_DPP_U32(0u, hi, 0x142, 0xa); break;
+    default: lo = UTM_DPP_U32(0u, lo, 0x143, 0xc); hi = UTM_DPP_U32(0u, hi, 0x143, 0xc); break;
+    }
+    return __builtin_bit_cast(double, ((u64)hi << 32) | lo);
+}
+__device__ __forceinline__ double wave_scan_f64(double v)  // +0.0 is the identity
+{
+    v += dpp_f64(v, 0x111, 0xf);
+    v += dpp_f64(v, 0x112, 0xf);
+    v += dpp_f64(v, 0x114, 0xf);
+    v += dpp_f64(v, 0x118, 0xf);
+    v += dpp_f64(v, 0x142, 0xa);
+    v += dpp_f64(v, 0x143, 0xc);
+    return v;
+}
 
 struct ParScratch {       // LDS
     unsigned wmap[16];
@@ -226,22 +266,25 @@ __device__ __forceinline__ double chain_parallel(const double *__restrict__ vals
         while (g >= offs[seg + 1]) ++seg;
         return vals[(size_t)seg * seg_cap + (g - offs[seg])];
     };
-    double acc = 0.0;
-    unsigned pos = 0;
-    while (pos < total) {
-        if (acc == 0.0) {  // 0 + a = a
+    // The first UTM_PAR_HEAD addends one by one (wave 0, registers only): a sum leaves a binade every few addends at
+    // its start, and every crossing would cost the scan a round of its own.
+    const unsigned head = total < UTM_PAR_HEAD ? total : UTM_PAR_HEAD;
+    if (wave == 0) {
+        double first = 0.0;
+        for (unsigned t = 0; t < head; t += 64) {
             int seg = 0;
-            acc = value_at(pos, seg);
-            ++pos;
-            continue;
+            first = ordered_sum64(first, t + lane < head ? value_at(t + lane, seg) : 0.0);
         }
-        const int e = (int)((__builtin_bit_cast(u64, acc) >> 52) & 0x7FF) - 1023;
-        const int scale = 52 - e;
-        const double m0 = ldexp(acc, scale);                 // M: integer in [2^52, 2^53)
-        const double limit = 9007199254740992.0 - m0;        // the sum of q reaching this = leaving the binade
-        const unsigned g0 = pos + (unsigned)tid * UTM_PAR_E;
-        double a[UTM_PAR_E], k[UTM_PAR_E];
-        int tie[UTM_PAR_E];
+        if (lane == 0) sc.crossed = first;
+    }
+    __syncthreads();
+    double acc = sc.crossed;
+    __syncthreads();
+    for (unsigned base = 0; base < total; base += 1024u * UTM_PAR_E) {
+        // this window's addends stay in registers until the window is used up: a round that ends at a binade crossing
+        // only moves `done` (addends in front of it count as 0 from then on) and re-runs the scans with the new unit
+        const unsigned g0 = base + (unsigned)tid * UTM_PAR_E;
+        double a[UTM_PAR_E];
         {
             int seg = 0;
             if (g0 < total) {  // binary search: last segment whose offset is <= g0
@@ -256,90 +299,90 @@ __device__ __forceinline__ double chain_parallel(const double *__restrict__ vals
 #pragma unroll
             for (int j = 0; j < UTM_PAR_E; ++j) a[j] = g0 + j < total ? value_at(g0 + j, seg) : 0.0;
         }
-        unsigned map = 2u;  // identity
+        const unsigned end = total - base > 1024u * UTM_PAR_E ? base + 1024u * UTM_PAR_E : total;
+        unsigned done = base > head ? base : head;  // addends [base, done) are in acc already
+        while (done < end) {
+            const int e = (int)((__builtin_bit_cast(u64, acc) >> 52) & 0x7FF) - 1023;
+            const int scale = 52 - e;
+            const double m0 = ldexp(acc, scale);                 // M: integer in [2^52, 2^53)
+            const double limit = 9007199254740992.0 - m0;        // the sum of q reaching this = leaving the binade
+            double k[UTM_PAR_E];
+            int tie[UTM_PAR_E];
+            unsigned map = 2u;  // identity
 #pragma unroll
-        for (int j = 0; j < UTM_PAR_E; ++j) {
-            const double x = ldexp(a[j], scale);             // a / U, exact (a power-of-two scaling)
-            const double fl = floor(x);
-            const double r = x - fl;                         // exact
-            tie[j] = r == 0.5;
-            k[j] = fl + (r > 0.5 ? 1.0 : 0.0);               // q unless a tie; a tie: k or k + 1
-            map = pm_then(map, tie[j] ? 0u : (low_bit(k[j]) ? 1u : 2u));
-        }
-        unsigned inc = map;  // inclusive scan of the maps over the wave, then over the waves
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned other = __shfl_up(inc, o, 64);
-            if (lane >= o) inc = pm_then(other, inc);
-        }
-        if (lane == 63) sc.wmap[wave] = inc;
-        __syncthreads();
-        unsigned before = 2u;
-        for (int w = 0; w < wave; ++w) before = pm_then(before, sc.wmap[w]);
-        unsigned excl = __shfl_up(inc, 1, 64);
-        if (lane == 0) excl = 2u;
-        int par = (pm_then(before, excl) >> low_bit(m0)) & 1;  // parity of M in front of this thread's first addend
-        double q[UTM_PAR_E], mine = 0.0;
-#pragma unroll
-        for (int j = 0; j < UTM_PAR_E; ++j) {
-            if (tie[j]) {
-                q[j] = k[j] + (double)((par + low_bit(k[j])) & 1);  // ... to the even neighbour
-                par = 0;
-            } else {
-                q[j] = k[j];
-                par ^= low_bit(k[j]);
+            for (int j = 0; j < UTM_PAR_E; ++j) {
+                const double x = g0 + j >= done ? ldexp(a[j], scale) : 0.0;  // a / U, exact (a power-of-two scaling)
+                const double fl = floor(x);
+                const double r = x - fl;                         // exact
+                tie[j] = r == 0.5;
+                k[j] = fl + (r > 0.5 ? 1.0 : 0.0);               // q unless a tie; a tie: k or k + 1
+                map = pm_then(map, tie[j] ? 0u : (low_bit(k[j]) ? 1u : 2u));
             }
-            mine += q[j];
-        }
-        double incs = mine;
+            const unsigned inc = wave_scan_maps(map);  // inclusive scan of the maps over the wave, then over the waves
+            if (lane == 63) sc.wmap[wave] = inc;
+            __syncthreads();
+            unsigned before = 2u;
+            for (int w = 0; w < wave; ++w) before = pm_then(before, sc.wmap[w]);
+            unsigned excl = __shfl_up(inc, 1, 64);
+            if (lane == 0) excl = 2u;
+            int par = (pm_then(before, excl) >> low_bit(m0)) & 1;  // parity of M in front of this thread's first addend
+            double q[UTM_PAR_E], mine = 0.0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const double other = __shfl_up(incs, o, 64);
-            if (lane >= o) incs += other;
-        }
-        if (lane == 63) sc.wsum[wave] = incs;
-        __syncthreads();
-        double in_front = 0.0, all = 0.0;
-        for (int w = 0; w < 16; ++w) {
-            const double t = sc.wsum[w];
-            in_front += w < wave ? t : 0.0;
-            all += t;
-        }
-        if (all < limit) {  // the whole window stays in the binade (uniform: every thread sees the same total)
-            acc = ldexp(m0 + all, -scale);
-            pos = total - pos > 1024u * UTM_PAR_E ? pos + 1024u * UTM_PAR_E : total;
-            continue;
-        }
-        // the first addend whose q takes M to 2^53 or beyond is added for real.  (The sum in front of this thread's
-        // addends comes from the previous lane's inclusive value, never from `incs - mine`: sums past 2^53 are no longer
-        // exact, and this thread's own addends may be what takes them there.)
-        double lanes_before = __shfl_up(incs, 1, 64);
-        if (lane == 0) lanes_before = 0.0;
-        double run = in_front + lanes_before, at = 0.0, addend = 0.0;
-        unsigned first = 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < UTM_PAR_E; ++j) {
-            if (first == 0xFFFFFFFFu && run + q[j] >= limit) {
-                first = g0 + j;
-                at = run;
-                addend = a[j];
+            for (int j = 0; j < UTM_PAR_E; ++j) {
+                if (tie[j]) {
+                    q[j] = k[j] + (double)((par + low_bit(k[j])) & 1);  // ... to the even neighbour
+                    par = 0;
+                } else {
+                    q[j] = k[j];
+                    par ^= low_bit(k[j]);
+                }
+                mine += q[j];
             }
-            run += q[j];
-        }
-        unsigned wmin = first;
+            const double incs = wave_scan_f64(mine);
+            if (lane == 63) sc.wsum[wave] = incs;
+            __syncthreads();
+            double in_front = 0.0, all = 0.0;
+            for (int w = 0; w < 16; ++w) {
+                const double t = sc.wsum[w];
+                in_front += w < wave ? t : 0.0;
+                all += t;
+            }
+            if (all < limit) {  // the rest of the window stays in the binade (uniform: every thread sees the same total)
+                acc = ldexp(m0 + all, -scale);
+                done = end;
+                continue;
+            }
+            // the first addend whose q takes M to 2^53 or beyond is added for real.  (The sum in front of this thread's
+            // addends comes from the previous lane's inclusive value, never from `incs - mine`: sums past 2^53 are no
+            // longer exact, and this thread's own addends may be what takes them there.)
+            double lanes_before = __shfl_up(incs, 1, 64);
+            if (lane == 0) lanes_before = 0.0;
+            double run = in_front + lanes_before, at = 0.0, addend = 0.0;
+            unsigned first = 0xFFFFFFFFu;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned other = __shfl_xor(wmin, o, 64);
-            wmin = other < wmin ? other : wmin;
+            for (int j = 0; j < UTM_PAR_E; ++j) {
+                if (first == 0xFFFFFFFFu && run + q[j] >= limit) {
+                    first = g0 + j;
+                    at = run;
+                    addend = a[j];
+                }
+                run += q[j];
+            }
+            unsigned wmin = first;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned other = __shfl_xor(wmin, o, 64);
+                wmin = other < wmin ? other : wmin;
+            }
+            if (lane == 0) sc.wcross[wave] = wmin;
+            __syncthreads();
+            unsigned where = 0xFFFFFFFFu;
+            for (int w = 0; w < 16; ++w) where = sc.wcross[w] < where ? sc.wcross[w] : where;
+            if (first == where) sc.crossed = ldexp(m0 + at, -scale) + addend;  // (exactly one thread owns that addend)
+            __syncthreads();
+            acc = sc.crossed;
+            done = where + 1;
         }
-        if (lane == 0) sc.wcross[wave] = wmin;
-        __syncthreads();
-        unsigned where = 0xFFFFFFFFu;
-        for (int w = 0; w < 16; ++w) where = sc.wcross[w] < where ? sc.wcross[w] : where;
-        if (first == where) sc.crossed = ldexp(m0 + at, -scale) + addend;  // (exactly one thread owns that addend)
-        __syncthreads();
-        acc = sc.crossed;
-        pos = where + 1;
     }
     return acc;
 }
