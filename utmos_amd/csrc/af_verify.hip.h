@@ -389,14 +389,24 @@ __device__ __forceinline__ double chain_parallel(const double *__restrict__ vals
 
 #define UTM_CHAIN_CAP 2048
 #define UTM_CHAIN_WPT 4  // consecutive words per lane and round: 4096 words (262,144 variants) per round
+// Blocks [0, UTM_MAX_CAND): one candidate each.  Blocks behind them: only when more than UTM_MAX_CAND candidates tie
+// within the error bound (cand_overflow) -- then every selectable sample is re-scored with the plain sequential
+// chain, one lane per sample (what a k_score_seq launch of its own did, at a launch per iteration).
 template <typename AF_T>
 __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chunks, int n_chunks,
-                                                const IterState *__restrict__ st, CandBuf *__restrict__ cand, ChainFast f)
+                                                const IterState *__restrict__ st, CandBuf *__restrict__ cand, ChainFast f,
+                                                const unsigned *__restrict__ act, u64 *__restrict__ cnt, double *__restrict__ fscore)
 {
     __shared__ double buf[UTM_CHAIN_CAP];
     __shared__ unsigned wtot[2][16];  // double buffered: one barrier per empty round
     __shared__ int dense;
-    if (st->done || !st->need_chain || st->cand_overflow || (int)blockIdx.x >= st->n_cand) return;
+    if (st->done || !st->need_chain) return;
+    if (blockIdx.x >= UTM_MAX_CAND) {
+        const unsigned i = (blockIdx.x - UTM_MAX_CAND) * 1024 + threadIdx.x;
+        if (st->cand_overflow && i < st->n_active) seq_score_sample<AF_T>(chunks, n_chunks, act[i], cnt, fscore);
+        return;
+    }
+    if (st->cand_overflow || (int)blockIdx.x >= st->n_cand) return;
     const unsigned s = cand->samp[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (f.counts && st->n_cand <= f.n_cand && f.n_segs <= UTM_PAR_MAX_SEGS) {

@@ -76,10 +76,10 @@ static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
     const unsigned blocks = (a_ub + 63) / 64;
     if (c->af_mode == UTM_AF_F32)
         hipExtLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, t.start, t.stop, 0, c->d_seq,
-                              (int)c->chunks.size(), c->d_st, c->d_act, c->d_cnt, c->d_fscore, 0);
+                              (int)c->chunks.size(), c->d_st, c->d_act, c->d_cnt, c->d_fscore);
     else
         hipExtLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, t.start, t.stop, 0, c->d_seq,
-                              (int)c->chunks.size(), c->d_st, c->d_act, c->d_cnt, c->d_fscore, 0);
+                              (int)c->chunks.size(), c->d_st, c->d_act, c->d_cnt, c->d_fscore);
 }
 
 // AF, dense phase: LDS AF tiles.  Every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache), so
@@ -100,7 +100,8 @@ static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
 // The streaming kernels (k_score_int, k_score_afs): grid = variant tiles x groups of samples.  Tile = the largest
 // of {32 (AF: 16), 8, 2} KiB that still yields >= UTM_MIN_WGS workgroups; group size such that the grid has about
 // UTM_TARGET_WGS workgroups (>> 256 CUs, small enough units for an even tail), at least one sample per wave.
-static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta = false, const IntLaunch &how = IntLaunch())
+static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta = false, const IntLaunch &how = IntLaunch(),
+                                   bool fold = false)
 {
     static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
     static const int min_wgs = tune_env("UTM_MIN_WGS", 128);  // (1024 before the pick moved into the launch: 8 KiB tiles now win down to the last iterations)
@@ -133,7 +134,7 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
 #define UTM_LAUNCH_AFS(S, Q)                                                                                              \
     hipExtLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,       \
                           ch.covered, ch.wp, afb, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,   \
-                          (unsigned)group, n_groups, delta ? ch.mask : nullptr)
+                          (unsigned)group, n_groups, (delta && !fold) ? ch.mask : nullptr, (delta && fold) ? ch.covered_alt : nullptr)
         if (steps == 32) UTM_LAUNCH_AFS(32, 8);  // second argument: queue depth per lane
         else if (steps == 16) UTM_LAUNCH_AFS(16, 16);
         else if (steps == 8) UTM_LAUNCH_AFS(8, 16);
@@ -144,6 +145,13 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
     else if (steps == 8) launch_score_int<8>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
     else if (steps == 4) launch_score_int<4>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
     else launch_score_int<2>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
+}
+
+// Every chunk's (covered, covered_alt) pair and the chain kernels' chunk tables change roles together.
+static void swap_covered(utm_ctx *c)
+{
+    for (auto &ch : c->chunks) std::swap(ch.covered, ch.covered_alt);
+    std::swap(c->d_seq, c->d_seq_alt);
 }
 
 // Enqueue the scoring of one iteration for every chunk (and the pending covered update).
@@ -175,11 +183,19 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, bool fuse_pi
                 else launch_score_streaming(c, ch, a_ub);
             }
             c->keep_valid = true;
-        } else {
+        } else if (remote_reads(c)) {
+            // the winner may sit on another GPU: one launch reads its column once and leaves the newly-covered mask
             for (auto &ch : c->chunks)
                 hipLaunchKernelGGL(k_newly_mask, dim3((unsigned)std::min<u64>(2048, (ch.wp + 255) / 256)), dim3(256), 0, c->stream,
                                    ch.covered, ch.cols, ch.wp, pending_of(c, ch, false), c->d_st, ch.mask);
             for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub, /*delta=*/true);
+        } else {
+            // the mask is made while the tiles are staged; the updated covered words land in the other buffer of each
+            // chunk's pair, which becomes the current one for everything enqueued from here on (utm_run undoes the
+            // swaps of launches that a finished loop skipped)
+            for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub, /*delta=*/true, IntLaunch(), /*fold=*/true);
+            swap_covered(c);
+            c->cov_swaps_enqueued += 1;
         }
     } else {
         if (remote_reads(c)) launch_apply_pending(c);  // remote column: read it once, not once per workgroup
@@ -240,8 +256,9 @@ static int enqueue_score_decr(utm_ctx *c)
 // Algorithmic HBM bytes of one scoring pass with `a` selectable local samples (SURVEY.md §8d "the
 // bytes that variant actually has to read"): active columns + covered read + winner column re-read + covered write;
 //   UTM_PASS_AF_FULL   + the per-variant AF table (a full AF pass, and every pass of the sequential AF kernel);
-//   UTM_PASS_AF_DELTA  + the newly-covered mask written once and read once; the AF values such a pass gathers are
-//                        counted from the counts' decrease (utm_run) -- it never reads the table as a whole.
+//   UTM_PASS_AF_DELTA  the AF values such a pass gathers are counted from the counts' decrease (utm_run) -- it never
+//                        reads the table as a whole; + the newly-covered mask written once and read once where a
+//                        separate launch makes it (winner columns read in place from another GPU).
 enum { UTM_PASS_PLAIN = 0, UTM_PASS_AF_FULL = 1, UTM_PASS_AF_DELTA = 2 };
 static i64 iteration_bytes(const utm_ctx *c, u64 a, int kind = -1)
 {
@@ -250,7 +267,7 @@ static i64 iteration_bytes(const utm_ctx *c, u64 a, int kind = -1)
     for (auto &ch : c->chunks) {
         b += (i64)((a + 3) * ch.w * 8);
         if (kind == UTM_PASS_AF_FULL) b += (i64)ch.n_var * (c->af_mode == UTM_AF_F64 && !c->af_fixed ? 8 : 4);
-        if (kind == UTM_PASS_AF_DELTA) b += (i64)(2 * ch.w * 8);
+        if (kind == UTM_PASS_AF_DELTA && remote_reads(c)) b += (i64)(2 * ch.w * 8);  // (a folded delta pass has no mask array)
     }
     return b;
 }
@@ -260,20 +277,18 @@ static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
 {
     if (!a.cand) return;
     hipLaunchKernelGGL(k_cand, dim3(1), dim3(256), 0, c->stream, a);
-    const unsigned blocks = (std::max(1u, c->active_ub) + 63) / 64;
+    const unsigned seq_blocks = (std::max(1u, c->active_ub) + 1023) / 1024;  // (only busy when the candidate list overflowed)
     const ChainFast &cf = c->chain_fast;
     if (c->af_mode == UTM_AF_F32) {
         if (cf.counts)
             hipLaunchKernelGGL(k_chain_fill<float>, dim3(cf.n_segs, cf.n_cand), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
-        hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand, cf);
-        hipLaunchKernelGGL(k_score_seq<float>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                           c->d_act, c->d_cnt, c->d_fscore, 1);
+        hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND + seq_blocks), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                           c->d_cand, cf, c->d_act, c->d_cnt, c->d_fscore);
     } else {
         if (cf.counts)
             hipLaunchKernelGGL(k_chain_fill<double>, dim3(cf.n_segs, cf.n_cand), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
-        hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st, c->d_cand, cf);
-        hipLaunchKernelGGL(k_score_seq<double>, dim3(blocks), dim3(64), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                           c->d_act, c->d_cnt, c->d_fscore, 1);
+        hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND + seq_blocks), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
+                           c->d_cand, cf, c->d_act, c->d_cnt, c->d_fscore);
     }
 }
 
@@ -368,6 +383,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // are delta passes (enqueue_score); the byte accounting below tells them apart
         const bool af_par = c->af_mode != UTM_AF_NONE && c->af_fixed && !decr;
         const bool first_is_full = af_par && !c->keep_valid;
+        const i64 swaps0 = c->cov_swaps_enqueued;
         for (i64 j = 0; j < n; ++j) {
             bool picked = false;
             if (decr) TRY(enqueue_score_decr(c));
@@ -391,6 +407,13 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         const i64 rows = c->iter - before;
         const i64 passes = std::min<i64>(n, rows + ((c->finished && c->h_st->tot < (i64)c->n_var_total && rows < n) ? 1 : 0));
         const unsigned a1 = c->active_ub;
+        {
+            // folded delta passes swap the covered pair when they are ENQUEUED; the ones a finished loop skipped wrote
+            // nothing, so an odd number of them leaves the roles one swap off
+            const i64 swapped = c->cov_swaps_enqueued - swaps0;
+            const i64 ran = std::max<i64>(0, passes - (first_is_full ? 1 : 0));
+            if (swapped > ran && ((swapped - ran) & 1)) swap_covered(c);
+        }
         for (i64 j = 0; j < passes; ++j) {
             const u64 drop = rows > 0 ? (u64)(a0 - a1) * (u64)std::min(j, rows) / (u64)rows : 0;
             const int kind = !af_par ? -1 : (j == 0 && first_is_full) ? UTM_PASS_AF_FULL : UTM_PASS_AF_DELTA;

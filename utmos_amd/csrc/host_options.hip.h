@@ -93,7 +93,8 @@ static int build_af_tables(utm_ctx *c)
         ch.afx = nullptr;
     }
     (void)hipFree(c->d_seq);
-    c->d_seq = nullptr;
+    (void)hipFree(c->d_seq_alt);
+    c->d_seq = c->d_seq_alt = nullptr;
     c->af_fixed = false;
     c->af_q = 0;
     if (c->af_mode == UTM_AF_NONE) { c->dirty_tables = false; return UTM_OK; }
@@ -145,10 +146,11 @@ static int build_af_tables(utm_ctx *c)
     } else {
         c->af_trunc = false;
     }
-    std::vector<SeqChunk> seq;
+    std::vector<SeqChunk> seq, seq_alt;
     for (size_t k = 0; k < c->chunks.size(); ++k) {
         Chunk &ch = c->chunks[k];
         const size_t n = ch.wp * 64;
+        if (c->af_fixed && !ch.covered_alt) HIP_TRY(hipMalloc(&ch.covered_alt, ch.wp * 8));
         if (c->af_fixed) {
             // the estimate's table: floor(a * 2^q) as mantissa << shift (af_fixed(), score_af.hip.h)
             std::vector<unsigned> fx(n, 0u);
@@ -176,9 +178,12 @@ static int build_af_tables(utm_ctx *c)
             HIP_TRY(copy_sync(c, ch.af, ch.h_af64.data(), ch.n_var * 8, hipMemcpyHostToDevice));
         }
         seq.push_back(SeqChunk{ch.cols, ch.covered, ch.af, ch.wp, ch.w});
+        seq_alt.push_back(SeqChunk{ch.cols, ch.covered_alt ? ch.covered_alt : ch.covered, ch.af, ch.wp, ch.w});
     }
     HIP_TRY(hipMalloc(&c->d_seq, seq.size() * sizeof(SeqChunk)));
     HIP_TRY(copy_sync(c, c->d_seq, seq.data(), seq.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&c->d_seq_alt, seq_alt.size() * sizeof(SeqChunk)));
+    HIP_TRY(copy_sync(c, c->d_seq_alt, seq_alt.data(), seq_alt.size() * sizeof(SeqChunk), hipMemcpyHostToDevice));
     // segment table + buffers of the chains' fast path
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     c->d_segs = nullptr;

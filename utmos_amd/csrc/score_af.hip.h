@@ -110,15 +110,18 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 // CAP = queue depth per LANE: every lane keeps its own little queue (slot-major in LDS, so a wave's
 // pushes are conflict free) -- no cross-lane prefix sum is needed to place an entry.
 // delta_mask == nullptr: full scoring against ~covered (adds to the accumulators, fuses the pending update).
-// delta_mask != nullptr: *delta* scoring -- the mask holds the variants the last winner newly covered
-// (k_newly_mask made it and already updated covered); their contribution is SUBTRACTED from the persistent
-// accumulators.  Same bytes streamed, but only the few newly covered bits take the queue/gather path.
+// delta_mask != nullptr or covered_out != nullptr: *delta* scoring -- against the variants the last winner newly
+// covered; their contribution is SUBTRACTED from the persistent accumulators.  Same bytes streamed, but only the few
+// newly covered bits take the queue/gather path.  The mask is either made while the tile is staged (covered_out: the
+// updated covered words go to the other buffer of a ping-pong pair) or was made beforehand by k_newly_mask (delta_mask:
+// the form for winners read in place from another GPU, which one launch should read once, not once per workgroup).
 template <int STEPS, int CAP>
 __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const unsigned *__restrict__ afbits, const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
-                                                   unsigned n_groups, const u64 *__restrict__ delta_mask)
+                                                   unsigned n_groups, const u64 *__restrict__ delta_mask,
+                                                   u64 *__restrict__ covered_out)
 {
     __shared__ v4u live[STEPS * 64];
     __shared__ unsigned queue[4][CAP][64];
@@ -128,7 +131,24 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
     const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
-    if (delta_mask) {
+    const bool delta = delta_mask || covered_out;
+    if (covered_out) {
+        // delta pass, mask made on the fly: newly covered = pending winner & ~covered.  Every group of the tile reads
+        // the OLD covered words -- `covered` is not written by this launch -- and group 0 writes covered | winner
+        // into the other buffer of the pair, which the host makes the current one for whatever it enqueues next
+        // (a writer in place would hand later groups an already updated tile, i.e. an empty mask).
+        const v4u *cv = reinterpret_cast<const v4u *>(covered + w0);
+        v4u *co = reinterpret_cast<v4u *>(covered_out + w0);
+        const u64 *wcol = pending_column(st, cols, wp, pend);
+        const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
+        const v4u zero4 = {0, 0, 0, 0};
+        for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
+            const v4u c = cv[i];
+            const v4u w = wc ? wc[i] : zero4;
+            if (grp == 0) co[i] = c | w;
+            live[i] = w & ~c;
+        }
+    } else if (delta_mask) {
         const v4u *mk = reinterpret_cast<const v4u *>(delta_mask + w0);
         for (int i = threadIdx.x; i < nsteps * 64; i += 256) live[i] = mk[i];
     } else {
@@ -216,8 +236,8 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
         if (n) {  // wave uniform
             const i64 total = wave_sum_u63(sum);
             if (lane == 0) {  // two's complement: adding the negated value subtracts
-                atomicAdd(&cnt[s], delta_mask ? (u64)0 - (u64)n : (u64)n);
-                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), delta_mask ? (u64)0 - (u64)total : (u64)total);
+                atomicAdd(&cnt[s], delta ? (u64)0 - (u64)n : (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), delta ? (u64)0 - (u64)total : (u64)total);
             }
         }
     }
@@ -230,15 +250,9 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
 // chunk, word after word, bit after bit.  Latency bound by construction.
 // ------------------------------------------------------------------------------------------------
 template <typename AF_T>
-__global__ __launch_bounds__(64) void k_score_seq(const SeqChunk *__restrict__ chunks, int n_chunks,
-                                                  const IterState *__restrict__ st, const unsigned *__restrict__ act,
-                                                  u64 *__restrict__ cnt, double *__restrict__ fscore, int only_on_overflow)
+__device__ __forceinline__ void seq_score_sample(const SeqChunk *__restrict__ chunks, int n_chunks, unsigned s, u64 *__restrict__ cnt,
+                                                 double *__restrict__ fscore)
 {
-    if (st->done) return;
-    if (only_on_overflow && !(st->need_chain && st->cand_overflow)) return;
-    const unsigned i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= st->n_active) return;
-    const unsigned s = act[i];
     double acc = 0.0;
     u64 n = 0;
     for (int c = 0; c < n_chunks; ++c) {
@@ -259,4 +273,15 @@ __global__ __launch_bounds__(64) void k_score_seq(const SeqChunk *__restrict__ c
     }
     cnt[s] = n;
     fscore[s] = acc;
+}
+
+template <typename AF_T>
+__global__ __launch_bounds__(64) void k_score_seq(const SeqChunk *__restrict__ chunks, int n_chunks,
+                                                  const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                  u64 *__restrict__ cnt, double *__restrict__ fscore)
+{
+    if (st->done) return;
+    const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= st->n_active) return;
+    seq_score_sample<AF_T>(chunks, n_chunks, act[i], cnt, fscore);
 }

@@ -120,6 +120,7 @@ struct Chunk {
     u64 off = 0; // word offset of this chunk inside a whole-column buffer
     u64 *cols = nullptr;
     u64 *covered = nullptr;
+    u64 *covered_alt = nullptr;  // AF delta passes write the updated mask here, then the two swap (host_loop.hip.h)
     void *af = nullptr;    // device: AF in its own type (float or double), wp*64 entries: chains read this
     float *af32 = nullptr; // device: float32 AF (== af when the AF is float32; float64 AF: not kept)
     unsigned *afx = nullptr;  // device: fixed-point table of the parallel estimate, wp*64 entries (af_fixed())
@@ -162,7 +163,8 @@ struct utm_ctx {
                               // ncclBroadcast from its owner, or utm_apply_records' winner_col
     u64 wincol_words = 0;
     bool remote_winner_test = false;  // UTM_TEST_REMOTE_WINNER=1 (tests): read a local winner from d_wincol too
-    SeqChunk *d_seq = nullptr;
+    SeqChunk *d_seq = nullptr;      // chunk table of the chain kernels, covered = the chunks' CURRENT buffers
+    SeqChunk *d_seq_alt = nullptr;  // ... the same with the other buffer of every pair (swapped together)
     CandBuf *d_cand = nullptr;
     ChainFast chain_fast{nullptr, 0, nullptr, nullptr, 0, 0};  // device buffers of the chains' fast path
     ChainSeg *d_segs = nullptr;
@@ -178,6 +180,7 @@ struct utm_ctx {
     i64 decr_iterations = 0;
     i64 brute_bytes = 0;
     u64 decr_entries_seen = 0, decr_gathers_seen = 0;
+    i64 cov_swaps_enqueued = 0;  // folded AF delta passes enqueued so far (each swaps the chunks' covered pairs)
     u64 cnt_sum_prev = 0;        // AF byte accounting: sum of the selectable samples' counts at the last batch boundary
     u64 *d_varcount = nullptr;
     bool varcount_valid = false;
@@ -310,6 +313,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     for (auto &ch : c->chunks) {
         (void)hipFree(ch.cols);
         (void)hipFree(ch.covered);
+        (void)hipFree(ch.covered_alt);
         if ((void *)ch.af32 != ch.af) (void)hipFree(ch.af32);
         (void)hipFree(ch.afx);
         (void)hipFree(ch.af);
@@ -323,7 +327,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
-    (void)hipFree(c->d_xbuf); (void)hipFree(c->d_wincol); (void)hipFree(c->d_seq); (void)hipFree(c->d_varcount);
+    (void)hipFree(c->d_xbuf); (void)hipFree(c->d_wincol); (void)hipFree(c->d_seq); (void)hipFree(c->d_seq_alt); (void)hipFree(c->d_varcount);
     if (c->h_st) (void)hipHostFree(c->h_st);
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);
