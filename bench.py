@@ -344,7 +344,31 @@ def main():
             return value
         return max(r[0] for r in transport.allgather((float(value), 0, 0)))
 
-    res = timed_steps(m, k_sel, args.steps, args.warmup, sync_max)
+    exchange_note = None
+    try:
+        res = timed_steps(m, k_sel, args.steps, args.warmup, sync_max)
+        failed = None
+    except device.nat.NativeError as exc:
+        if transport is None:
+            raise
+        res, failed = None, exc
+    if transport is not None and not transport.agree(failed is None):
+        # a rank lost a record in the mailboxes (the wait is bounded: every rank comes back within seconds): the same
+        # steps through RCCL instead, and the line says so
+        if exchange != "mailboxes":
+            raise SystemExit(f"bench.py rank {rank}: the {exchange} exchange failed ({failed})")
+        exchange_note = f"the device mailboxes passed their self-test but failed in the loop ({failed}); measured through RCCL instead"
+        m.p2p_use_mailboxes(False)
+        err = None
+        try:
+            m.comm_init(rank, world, uid)
+        except device.nat.NativeError as exc:
+            err = exc
+        if not transport.agree(err is None):
+            raise SystemExit(f"bench.py rank {rank}: no working exchange (mailboxes: {failed}; RCCL: {err})")
+        exchange = "rccl"
+        args.exchange = "rccl"
+        res = timed_steps(m, k_sel, args.steps, args.warmup, sync_max)
     st = res["stats"]
     idx, new, _ = res["rows"]
 
@@ -439,7 +463,7 @@ def main():
                    "iterations_per_step": head["iterations_per_step"], "tot_captured": head["tot_captured"], "chunks": head["chunks"],
                    "seed": args.seed, "sharding": f"sample axis over {world} GPU(s)" if world > 1 else "none",
                    "generator_s": head["generator_s"], "af_verified_parallel": st["af_fixed_point"] if args.af else None},
-        "exchange": exchange, "rccl_ranks": final_stats["rccl_ranks"] if exchange == "rccl" else None,
+        "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": final_stats["rccl_ranks"] if exchange == "rccl" else None,
         "p2p_replica_bytes": final_stats["p2p_replica_bytes"] if world > 1 else None,
         "also_exchange": also_exchange,
         "scoring": "decremental after the first passes (bytes = what this variant actually reads; NOT the brute-force "

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Collect the round's evidence on a GPU box (run from the repo root through gpurun); writes gpurun_out/prof_<tag>/ and
+# condensed files under gpurun_out/profiles_r02/ (copy those into profiles/).
+#   tools/collect_profiles.sh r02
+set -o pipefail
+tag=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$R/gpurun_out/profiles_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+echo "== headline (unprofiled), default invocation"
+python3 $R/bench.py --steps 5 --warmup 2 > $out/${tag}_cfg2_bench.json 2> $out/${tag}_cfg2_bench.err || exit 1
+for cfg in cfg2 cfg3 cfg1; do
+  extra="--workload $cfg"; [ $cfg = cfg2 ] && extra="--no-also"
+  prefix="void k_score_int"; [ $cfg = cfg3 ] && prefix="void k_score_afs,void k_score_afq"
+  echo "== $cfg kernel trace + stats"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_${cfg}_kt -- python3 $R/bench.py $extra --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_${cfg}_bench_under_rocprofv3.json 2> /dev/null || exit 1
+  for counter in FETCH_SIZE WRITE_SIZE; do
+    echo "== $cfg pmc $counter"
+    rocprofv3 --pmc $counter --output-format csv -d $R/gpurun_out/prof_${tag}_${cfg}_$counter -- python3 $R/bench.py $extra --steps 1 --warmup 0 --no-cpu-baseline --no-roofline-pass --no-also --pmc-traffic off > /dev/null 2>&1 || exit 1
+  done
+  (cd $R && mkdir -p profiles_tmp && python3 tools/summarize_profile.py ${tag}_${cfg} gpurun_out/prof_${tag}_${cfg}_kt gpurun_out/prof_${tag}_${cfg}_FETCH_SIZE gpurun_out/prof_${tag}_${cfg}_WRITE_SIZE "bench.py $extra, one step" "$prefix" > /dev/null) || exit 1
+  python3 $R/tools/trace_gaps.py $R/gpurun_out/prof_${tag}_${cfg}_kt > $out/${tag}_${cfg}_stream_time.txt 2>&1
+  find $R/gpurun_out/prof_${tag}_${cfg}_kt $R/gpurun_out/prof_${tag}_${cfg}_FETCH_SIZE $R/gpurun_out/prof_${tag}_${cfg}_WRITE_SIZE -name "*.csv" -size +3M -delete
+done
+echo "== float64 AF (the reference's in-memory --af values)"
+python3 $R/bench.py --af --af-dtype f64 --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_bench.json 2>/dev/null
+echo "== decremental (optional mode, reported separately)"
+python3 $R/bench.py --decremental --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_cfg2_decremental_bench.json 2>/dev/null
+cp $R/profiles/${tag}_* $out/ 2>/dev/null
+ls -la $out
