@@ -24,6 +24,18 @@
  *   - sample states follow select.py:169-179: 1 selectable, 0 already used (covers), 2 excluded.  A used sample
  *     covers on EVERY shard: utm_reset fetches a remote one through the P2P mapping or an ncclBroadcast, and
  *     fails with UTM_ESTATE on a shard that has neither.
+ *
+ * Environment.  None of these changes a result; they move launch shapes and thresholds (tools/tune.py sweeps them)
+ * or are test hooks.  The first context of a process lists on stderr the ones that are set.
+ *   UTM_TARGET_WGS (32768)    workgroups a scoring launch aims for          UTM_MIN_WGS (128), UTM_MIN_WGS_BIG (8192)
+ *   UTM_TILE_STEPS (auto)     force the covered tile to 32/16/8/4/2 KiB     smallest grids the 8 KiB / 32 KiB tiles are used for
+ *   UTM_NT_LOADS (auto)       non-temporal column loads on/off              UTM_NT_MIN_MB (512) matrix size from which they are used
+ *   UTM_FUSE_PICK (1)         pick inside the scoring launch (one shard, integer scores)
+ *   UTM_PICK_THREADS (auto)   threads of the stand-alone k_pick             UTM_BATCH (256; AF 64) iterations between host syncs
+ *   UTM_AF_STEPS (16), UTM_AF_SWITCH (0.2), UTM_AF_TARGET_WGS (16384)       AF kernels: tile, dense->streaming switch, grid
+ *   UTM_DECR_FIRST_BATCH (8), UTM_DECR_INTERLEAVED (1)                      decremental mode: first batch size, second copy on/off
+ *   UTM_P2P_REPLICATE (1)     copy the peers' columns once (0: read winners in place over the mappings)
+ *   UTM_TEST_REMOTE_WINNER (0) test hook: read local winners from the exchange's winner-column buffer too
  */
 #ifndef UTMOS_HIP_H
 #define UTMOS_HIP_H

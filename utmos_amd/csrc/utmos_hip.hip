@@ -253,9 +253,31 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
     return p;
 }
 
+// Every environment variable the library reads (include/utmos_hip.h "Environment" documents them).  They only move
+// launch shapes, thresholds and test hooks -- never results -- but a value left behind by an experiment should not go
+// unnoticed: the first context of a process names the ones that are set, once, on stderr.
+static const char *const g_env_knobs[] = {
+    "UTM_TARGET_WGS", "UTM_MIN_WGS", "UTM_MIN_WGS_BIG", "UTM_TILE_STEPS", "UTM_NT_LOADS", "UTM_NT_MIN_MB", "UTM_FUSE_PICK",
+    "UTM_PICK_THREADS", "UTM_BATCH", "UTM_AF_STEPS", "UTM_AF_SWITCH", "UTM_AF_TARGET_WGS", "UTM_DECR_FIRST_BATCH",
+    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER"};
+static void report_env_once()
+{
+    static bool said = false;
+    if (said) return;
+    said = true;
+    char line[1024];
+    size_t used = 0;
+    for (const char *name : g_env_knobs) {
+        const char *v = getenv(name);
+        if (v && *v && used < sizeof line - 64) used += (size_t)snprintf(line + used, sizeof line - used, " %s=%.24s", name, v);
+    }
+    if (used) fprintf(stderr, "libutmos_hip: environment overrides in effect:%s\n", line);
+}
+
 extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_sample, uint32_t n_samp_local,
                               uint32_t flags, utm_ctx **out)
 {
+    report_env_once();
     if (!out) return fail(UTM_EINVAL, "out is NULL");
     if (n_samp_total == 0 || n_samp_local == 0 || (u64)first_sample + n_samp_local > n_samp_total)
         return fail(UTM_EINVAL, "bad sample range: total %u first %u local %u", n_samp_total, first_sample, n_samp_local);
