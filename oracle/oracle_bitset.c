@@ -5,7 +5,7 @@
  *
  * It restates /root/reference/utmos/select.py on the layout the GPU uses, so that GPU
  * results can be checked at sizes where the row-major numpy restatement
- * (oracle/utmos_oracle.py, pinned on the reference's golden TSVs) is too slow.  The two
+ * (oracle/utmos_oracle.py, pinned on the reference's golden TSVs and on traces of its own code; this file is checked against the same traces) is too slow.  The two
  * oracles are checked against each other in tests/test_oracle_bitset.py.
  *
  *   score   select.py:33-41   a variant is skipped when a *used* (state 0) sample carries it;

@@ -14,11 +14,13 @@ What it restates (paths relative to /root/reference):
   greedy              utmos/select.py:69-112  (the h5 compaction branch :116-137 is result-neutral and omitted)
   format_row          utmos/select.py:102-108, 445
 
-Parity pin: every golden TSV the reference's own suite uses for this path
+Parity pins: (1) every golden TSV the reference's own suite uses for this path
 (repo_utils/utmos_ssshtests.sh:81-235 -> tests/golden/answer_key/*.txt) is reproduced
 byte-for-byte by tests/test_oracle_golden.py from the re-encoded fixtures
-(tests/golden/*.npz, made by tools/make_golden.py).  The reference itself is not
-importable here (h5py, truvari, scikit-allel absent; not stubbed), so the goldens are the pin.
+(tests/golden/*.npz, made by tools/make_golden.py); (2) outputs of the reference's own code,
+imported in the build container by tools/make_traces.py (tests/golden/traces/*.json: TSVs, winners
+and float64 scores of 24 cases the goldens do not reach, and the --count table), are reproduced by
+tests/test_reference_traces.py -- by this file and by oracle_bitset.c.
 """
 import numpy as np
 
