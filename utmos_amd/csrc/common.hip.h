@@ -46,6 +46,14 @@ struct IterState {
     u64 cnt_sum;        // at the end of the last batch
 };
 
+// The first 32 bytes of IterState: what a scoring workgroup needs at its start, fetched with one scalar load.
+struct IterHead {
+    int done, prev_valid, prev_local, prev_rank;
+    i64 prev_gidx;
+    unsigned n_active, best_pos;
+};
+static_assert(sizeof(IterHead) == 32, "IterHead mirrors the head of IterState");
+
 #define UTM_MAX_CAND 64
 struct CandBuf {
     unsigned pos[UTM_MAX_CAND];   // position in act[]
@@ -167,7 +175,8 @@ struct Pending {
 };
 
 // Winner column of the previous iteration (base of the chunk's column), or nullptr.
-__device__ __forceinline__ const u64 *pending_column(const IterState *st, const u64 *cols, u64 wp, const Pending &p)
+template <typename STATE>
+__device__ __forceinline__ const u64 *pending_column(const STATE *st, const u64 *cols, u64 wp, const Pending &p)
 {
     if (!st->prev_valid) return nullptr;
     if (st->prev_local >= 0) return cols + (u64)st->prev_local * wp;

@@ -47,8 +47,26 @@ __global__ __launch_bounds__(256, UTM_SCORE_WAVES(STEPS)) void k_score_int(const
                                                    unsigned by_pos, const PickArgs pa)
 {
     __shared__ v4u live[STEPS * 64];  // ~covered of this tile, STEPS KiB
-    if (st->done) return;             // (uniform over the launch: only a launch's last workgroup ever sets it)
+    // Everything this workgroup needs from memory before it can request its columns is asked for in ONE go -- the loop
+    // state (done flag, selectable count, where the pending winner's column is) and this wave's first two entries of
+    // act[] (read ahead of the bounds that say whether they count: act[] is padded) -- instead of flag -> count ->
+    // index -> column, four dependent round trips at the start of every workgroup and of every launch.
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned tile, grp;
+    const bool has_unit = tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp);
+    const unsigned lo = grp * group_size;
+    unsigned i = lo + wave;
+    const bool in_act = has_unit && i + 4 < pa.n_local + UTM_PICK_PAD;  // (inside the padded array)
+    unsigned s = in_act ? act[i] : 0;
+    unsigned s_next = in_act ? act[i + 4] : 0;
+    // (inline asm: left to itself the compiler fetches the flag first and sinks the other fields' loads below the branch
+    // on it, one round trip each)
+    typedef unsigned v8u __attribute__((ext_vector_type(8)));
+    v8u raw;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(raw) : "s"(st) : "memory");
+    const IterHead head = __builtin_bit_cast(IterHead, raw);
+    const unsigned n_active = head.n_active;
+    if (head.done) return;  // (uniform over the launch: only a launch's pick ever sets it)
     // the picker: one block behind the scoring grid (dispatched last: it starts polling when the launch is nearly over;
     // as the first block it polled all launch long and cost 2 %)
     if (FUSED && blockIdx.x == gridDim.x - 1) {
@@ -56,16 +74,12 @@ __global__ __launch_bounds__(256, UTM_SCORE_WAVES(STEPS)) void k_score_int(const
         fused_pick(pa, n_tiles, reinterpret_cast<IntCand *>(&live[0]));
         return;
     }
-    if (!tile_of_block(wp, STEPS * UTM_STEP_WORDS, n_groups, tile, grp)) return;
+    if (!has_unit) return;
     const u64 w0 = (u64)tile * STEPS * UTM_STEP_WORDS;
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
     const bool full = nsteps == STEPS;
-
-    const unsigned n_active = st->n_active;
-    const unsigned lo = grp * group_size;
     const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int U = STEPS < 8 ? STEPS : 8;  // loads in flight per wave: U KiB
 #define UTM_COL_LOAD(ptr) (NT ? __builtin_nontemporal_load(ptr) : *(ptr))
     // One batch = U KiB of a column.  Full tiles use immediate offsets; the last tile of a column may be shorter
@@ -102,15 +116,12 @@ __global__ __launch_bounds__(256, UTM_SCORE_WAVES(STEPS)) void k_score_int(const
     // two do not depend on each other: a short-lived workgroup would otherwise spend half its life waiting for
     // the tile, then again for its columns), and a sample's successor (index from act[], then its first U KiB) is
     // requested before the sample's reduction and atomic.
-    unsigned i = lo + wave;
-    unsigned s = i < hi ? act[i] : 0;
-    unsigned s_next = i + 4 < hi ? act[i + 4] : 0;
     const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
     v4u x[U];
     if (i < hi) { UTM_BATCH_LOAD(0) }
 
     v4u *cv = reinterpret_cast<v4u *>(covered + w0);
-    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
+    const u64 *wcol = pend.fuse ? pending_column(&head, cols, wp, pend) : nullptr;
     const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
     for (int k = threadIdx.x; k < nsteps * 64; k += 256) {
         v4u c = cv[k];
