@@ -37,7 +37,7 @@ struct LaunchTimer {
 // the launch (its last workgroup) or left to a k_pick launch.
 struct IntLaunch {
     bool by_pos = true;
-    bool fused = false;
+    int fused = 0;  // 0: a k_pick launch follows; 1: pick inside the launch (only shard); 2: pick + mailbox exchange inside
 };
 
 template <int STEPS>
@@ -50,12 +50,15 @@ static void launch_score_int(utm_ctx *c, const LaunchTimer &t, const Chunk &ch, 
     UTM_TIMED_LAUNCH(t, (k_score_int<STEPS, NT, FUSED>), dim3(blocks + (FUSED ? 1u : 0u)), dim3(256), cols, ch.covered, ch.wp,       \
                      pending_of(c, ch, true), (const IterState *)c->d_st, (const unsigned *)c->d_act, c->d_cnt, group, n_groups,   \
                      how.by_pos ? 1u : 0u, pa)
-    if (how.fused) {
-        if (nt) UTM_LAUNCH_INT(true, true);
-        else UTM_LAUNCH_INT(false, true);
+    if (how.fused == 2) {
+        if (nt) UTM_LAUNCH_INT(true, 2);
+        else UTM_LAUNCH_INT(false, 2);
+    } else if (how.fused == 1) {
+        if (nt) UTM_LAUNCH_INT(true, 1);
+        else UTM_LAUNCH_INT(false, 1);
     } else {
-        if (nt) UTM_LAUNCH_INT(true, false);
-        else UTM_LAUNCH_INT(false, false);
+        if (nt) UTM_LAUNCH_INT(true, 0);
+        else UTM_LAUNCH_INT(false, 0);
     }
 #undef UTM_LAUNCH_INT
 }
@@ -158,7 +161,7 @@ static void swap_covered(utm_ctx *c)
 // `fuse_pick`: the caller wants the iteration's pick too and nothing else in between (utm_run on the only shard,
 // integer scores): it then rides in the last chunk's scoring launch and *fused is set; `by_sample` keeps the counts
 // indexed by sample for callers that read them back per sample (utm_peek_scores).
-static int enqueue_score(utm_ctx *c, bool force_sequential = false, bool fuse_pick = false, bool *fused = nullptr,
+static int enqueue_score(utm_ctx *c, bool force_sequential = false, int fuse_pick = 0, bool *fused = nullptr,
                          bool by_sample = false)
 {
     if (fused) *fused = false;
@@ -205,7 +208,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, bool fuse_pi
         for (size_t k = 0; k < c->chunks.size(); ++k) {
             // (weighted scores are float64 products: they stay with k_pick, the fused pick compares integer counts)
             // ... and so do the full passes of a decremental run (they mirror their counts by sample)
-            how.fused = fuse_pick && fuse_env && !by_sample && !c->have_weights && !c->decr_enabled && k + 1 == c->chunks.size();
+            how.fused = (fuse_pick && fuse_env && !by_sample && !c->have_weights && !c->decr_enabled && k + 1 == c->chunks.size()) ? fuse_pick : 0;
             launch_score_streaming(c, c->chunks[k], a_ub, false, how);
             if (how.fused && fused) *fused = true;
         }
@@ -384,10 +387,12 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         const bool af_par = c->af_mode != UTM_AF_NONE && c->af_fixed && !decr;
         const bool first_is_full = af_par && !c->keep_valid;
         const i64 swaps0 = c->cov_swaps_enqueued;
+        // where the pick runs: inside the scoring launch on the only shard (1) and on a shard of the mailbox exchange (2)
+        const int fuse_mode = (c->n_ranks > 1 && c->mbox_ok) ? 2 : (c->n_ranks == 1 && c->n_local == c->n_total && !c->comm) ? 1 : 0;
         for (i64 j = 0; j < n; ++j) {
             bool picked = false;
             if (decr) TRY(enqueue_score_decr(c));
-            else TRY(enqueue_score(c, false, /*fuse_pick=*/c->n_ranks == 1 && c->n_local == c->n_total && !c->comm, &picked));
+            else TRY(enqueue_score(c, false, fuse_mode, &picked));
             if (!picked) TRY(enqueue_pick_and_exchange(c, decr));
             if (af_par && j == 0 && first_is_full) hipLaunchKernelGGL(k_count_sum, dim3(1), dim3(1024), 0, c->stream, c->d_st, c->d_act, c->d_cnt, 1);
             if (c->n_ranks == 1 && c->active_ub > 0) c->active_ub -= 1;  // exact while the loop is alive

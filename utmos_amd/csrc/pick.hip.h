@@ -98,8 +98,60 @@ __device__ __forceinline__ void decide_single(const PickArgs &a, const Cand &bes
     if (p.tot + best.cnt >= a.n_var_total) st->done = 1;
 }
 
-// The pick of an unweighted integer-score iteration on the only shard, run INSIDE the scoring launch by its extra
-// last block (k_score_int<.., FUSED>): same decision as k_pick<0>.  The count words (indexed by position in
+// Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
+// landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
+#define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
+__device__ __forceinline__ bool mbox_wait(const Mailbox *slot, u64 expected, Rec *out)
+{
+    for (unsigned spin = 0; spin < UTM_MBOX_SPINS; ++spin) {
+        if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == expected) {
+            out->score = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&slot->score), __ATOMIC_RELAXED,
+                                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+            out->idx = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            out->new_count = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->new_count), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_SYSTEM);
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    return false;
+}
+
+// Device-side exchange, both ends, then the decision -- called by EVERY thread of a workgroup (>= n_ranks threads)
+// once thread 0 has written this shard's record into recs[rank] and the caller has passed a barrier.  One lane per
+// destination shard stores the record into that shard's mailbox slot [seq & 1][my rank] -- payload first, sequence
+// number last (release, system scope) -- and collects that shard's record of the same exchange from the local mailbox.
+__device__ __forceinline__ void mailbox_exchange_and_decide(const PickArgs &a, int *late /* LDS, set to 0 before the barrier */)
+{
+    IterState *st = a.st;
+    if ((int)threadIdx.x < a.n_ranks) {
+        const Rec mine = *rec_of(a, a.rank);
+        const u64 seq = st->xseq + 1;
+        Mailbox *dst = a.peer_mbox[threadIdx.x] + (seq & 1) * a.n_ranks + a.rank;
+        __hip_atomic_store(reinterpret_cast<u64 *>(&dst->score), __builtin_bit_cast(u64, mine.score), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<u64 *>(&dst->idx), (u64)mine.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(reinterpret_cast<u64 *>(&dst->new_count), (u64)mine.new_count, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const Mailbox *slot = a.mbox + (seq & 1) * a.n_ranks + threadIdx.x;
+        if (!mbox_wait(slot, seq, rec_of(a, threadIdx.x))) *late = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (*late) {
+            st->xerror = 1;  // a shard went away: end the loop, the host reports it
+            st->done = 1;
+        } else {
+            st->xseq += 1;
+            decide(a);
+        }
+    }
+}
+
+// The pick of an unweighted integer-score iteration, run INSIDE the scoring launch by its extra last block
+// (k_score_int<.., FUSED>): FUSED = 1 on the only shard (same decision as k_pick<0>), FUSED = 2 on a shard whose
+// records travel through the device mailboxes (same exchange and decision as k_pick<2>).  The count words (indexed by position in
 // act[]) are being written by the scoring workgroups' agent-scope atomics while this runs; each partial carries
 // 2^40 on top of its count, so a word is final once its upper bits equal the number of variant tiles.  Words are
 // read with returning agent-scope atomics (add 0) -- the coherent read of a word other CUs update atomically --
@@ -124,6 +176,7 @@ __device__ __forceinline__ bool better_int(const IntCand &a, const IntCand &b)
 {
     return a.cnt > b.cnt || (a.cnt == b.cnt && a.s < b.s);
 }
+template <int FUSED>
 __device__ __forceinline__ void fused_pick(const PickArgs &a, unsigned n_tiles, IntCand *fbest /* LDS, 4 entries + flag */)
 {
     IterState *st = a.st;
@@ -183,41 +236,29 @@ __device__ __forceinline__ void fused_pick(const PickArgs &a, unsigned n_tiles, 
     if ((threadIdx.x & 63) == 0) fbest[threadIdx.x >> 6] = best;
     if (failed) *any_failed = 1;
     __syncthreads();
+    int *late = any_failed + 1;
     if (threadIdx.x == 0) {
+        *late = 0;
         if (*any_failed) {
             st->xerror = 2;
             st->done = 1;
-            return;
+        } else {
+            for (int w4 = 1; w4 < 4; ++w4)
+                if (better_int(fbest[w4], best)) best = fbest[w4];
+            const Cand win{(double)best.cnt, (i64)a.first + best.s, (i64)best.cnt, best.pos};
+            Rec *rc = rec_of(a, a.rank);
+            rc->score = n_active ? win.val : 0.0;
+            rc->idx = n_active ? win.gidx : -1;
+            rc->new_count = n_active ? win.cnt : 0;
+            st->best_pos = win.pos;
+            if (FUSED == 1) decide_single(a, win, n_active, pre);
         }
-        for (int w4 = 1; w4 < 4; ++w4)
-            if (better_int(fbest[w4], best)) best = fbest[w4];
-        const Cand win{(double)best.cnt, (i64)a.first + best.s, (i64)best.cnt, best.pos};
-        Rec *rc = rec_of(a, a.rank);
-        rc->score = n_active ? win.val : 0.0;
-        rc->idx = n_active ? win.gidx : -1;
-        rc->new_count = n_active ? win.cnt : 0;
-        st->best_pos = win.pos;
-        decide_single(a, win, n_active, pre);
     }
-}
-
-// Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
-// landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
-#define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
-__device__ __forceinline__ bool mbox_wait(const Mailbox *slot, u64 expected, Rec *out)
-{
-    for (unsigned spin = 0; spin < UTM_MBOX_SPINS; ++spin) {
-        if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == expected) {
-            out->score = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&slot->score), __ATOMIC_RELAXED,
-                                                                      __HIP_MEMORY_SCOPE_SYSTEM));
-            out->idx = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            out->new_count = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&slot->new_count), __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_SYSTEM);
-            return true;
-        }
-        __builtin_amdgcn_s_sleep(16);
+    if (FUSED == 2) {
+        __syncthreads();
+        if (*any_failed) return;  // (uniform: an internal error ends the loop on this shard; the peers time out on its record)
+        mailbox_exchange_and_decide(a, late);
     }
-    return false;
 }
 
 // MODE 0: single shard -- pick and decide.  1: write this shard's record into its exchange slot.
@@ -226,7 +267,6 @@ template <int MODE>
 __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
 {
     __shared__ Cand wbest[16];
-    __shared__ Rec srec;
     __shared__ int late;
     IterState *st = a.st;
     if (st->done) return;
@@ -288,12 +328,7 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
         rc->idx = n_active ? best.gidx : -1;
         rc->new_count = n_active ? best.cnt : 0;
         st->best_pos = best.pos;
-        if (MODE == 2) {
-            late = 0;
-            srec.score = rc->score;
-            srec.idx = rc->idx;
-            srec.new_count = rc->new_count;
-        }
+        if (MODE == 2) late = 0;
         if (a.list_n) {
             u64 n_l = 0;
             for (int c = 0; c < a.n_chunks; ++c) {
@@ -307,30 +342,7 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
     }
     if (MODE == 2) {
         __syncthreads();
-        if ((int)threadIdx.x < a.n_ranks) {
-            // one lane per destination shard; payload first, sequence number last (release, system scope)
-            const u64 seq = st->xseq + 1;
-            Mailbox *dst = a.peer_mbox[threadIdx.x] + (seq & 1) * a.n_ranks + a.rank;
-            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->score), __builtin_bit_cast(u64, srec.score), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->idx), (u64)srec.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->new_count), (u64)srec.new_count, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            // ... and collect that shard's record of the same exchange from the local mailbox
-            const Mailbox *slot = a.mbox + (seq & 1) * a.n_ranks + threadIdx.x;
-            if (!mbox_wait(slot, seq, rec_of(a, threadIdx.x))) late = 1;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (late) {
-                st->xerror = 1;  // a shard went away: end the loop, the host reports it
-                st->done = 1;
-            } else {
-                st->xseq += 1;
-                decide(a);
-            }
-        }
+        mailbox_exchange_and_decide(a, &late);
     }
 }
 

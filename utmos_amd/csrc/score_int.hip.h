@@ -29,7 +29,8 @@ __device__ __forceinline__ bool tile_of_block(u64 wp, unsigned tile_words, unsig
 // + one ds_read_b128 + 4x(v_and, v_bcnt) per step, a wave reduction and ONE 64-bit atomic per
 // (sample, tile).  Integer adds: exact and order independent.
 // ------------------------------------------------------------------------------------------------
-// FUSED: the pick of the iteration (mask / weight / argmax / decide, pick.hip.h) runs inside the scoring launch,
+// FUSED (1: the only shard, 2: a shard exchanging through the device mailboxes): the pick of the iteration (mask /
+// argmax / [exchange] / decide, pick.hip.h) runs inside the scoring launch,
 // in one extra workgroup (the grid's last block) -- no k_pick launch, no kernel boundary between scoring and pick.
 // Nobody signals and nobody waits on the scoring side: every (sample, tile) partial is added to the sample's
 // count word as `count + 2^40`, so bits 40.. of a count word say how many tile partials it holds, and the picker
@@ -39,7 +40,7 @@ __device__ __forceinline__ bool tile_of_block(u64 wp, unsigned tile_words, unsig
 #ifndef UTM_SCORE_WAVES
 #define UTM_SCORE_WAVES(STEPS) 1  // (forcing 8 waves/SIMD on the small tiles spilled the picker's registers: slower)
 #endif
-template <int STEPS, bool NT, bool FUSED>
+template <int STEPS, bool NT, int FUSED>
 __global__ __launch_bounds__(256, UTM_SCORE_WAVES(STEPS)) void k_score_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, UTM_SCORE_WAVES(STEPS)) void k_score_int(const
     // as the first block it polled all launch long and cost 2 %)
     if (FUSED && blockIdx.x == gridDim.x - 1) {
         const unsigned n_tiles = (unsigned)((wp + STEPS * UTM_STEP_WORDS - 1) / (STEPS * UTM_STEP_WORDS));
-        fused_pick(pa, n_tiles, reinterpret_cast<IntCand *>(&live[0]));
+        fused_pick<FUSED>(pa, n_tiles, reinterpret_cast<IntCand *>(&live[0]));
         return;
     }
     if (!has_unit) return;
