@@ -315,3 +315,68 @@ def test_text_vcf_reader_on_the_build_authored_fixture(golden_dir):
     alleles = [a for cell in text[0][9:] for a in cell.split(":")[0].replace("|", "/").split("/") if a != "."]
     want = max(alleles.count("1"), alleles.count("2")) / len(alleles)
     assert d["AF"][0, 0] == want
+
+
+class _EchoTransport:
+    """A transport in which every other rank answers exactly like this one (enough to walk connect_shards' branches)."""
+    rank, world = 0, 2
+
+    def allgather(self, record):
+        return [tuple(record), tuple(record)]
+
+    def allgather_bytes(self, blob):
+        return [blob, blob]
+
+    def agree(self, ok):
+        return bool(ok)
+
+
+class _ScriptedShard:
+    def __init__(self, export=True, imp=True, selftest=True, comm=True):
+        self.script = dict(export=export, imp=imp, selftest=selftest, comm=comm)
+        self.calls = []
+        self.p2p = False
+
+    def p2p_export(self):
+        self.calls.append("export")
+        if not self.script["export"]:
+            raise RuntimeError("no hipIpc")
+        return b"x" * 8
+
+    def p2p_import(self, rank, blobs):
+        self.calls.append("import")
+        if not self.script["imp"]:
+            raise RuntimeError("cannot map")
+        self.p2p = True
+
+    def p2p_selftest(self):
+        self.calls.append("selftest")
+        return self.script["selftest"]
+
+    def p2p_use_mailboxes(self, on):
+        self.calls.append(f"mailboxes={on}")
+
+    def comm_init(self, rank, world, uid):
+        self.calls.append("comm_init")
+        if not self.script["comm"]:
+            raise RuntimeError("RCCL refused")
+
+
+def test_connect_shards_order_mailboxes_then_rccl_then_error():
+    """sharded.connect_shards: mailboxes when every step works on every rank, else RCCL, else an error -- there is no
+    host-staged product path to fall back to."""
+    from utmos_amd.sharded import connect_shards
+    s = _ScriptedShard()
+    assert connect_shards(s, _EchoTransport(), b"id") == "mailboxes" and s.calls == ["export", "import", "selftest", "mailboxes=True"]
+    for broken in ("export", "imp", "selftest"):
+        s = _ScriptedShard(**{broken: False})
+        assert connect_shards(s, _EchoTransport(), b"id") == "rccl" and s.calls[-1] == "comm_init" and "mailboxes=True" not in s.calls
+    s = _ScriptedShard()
+    assert connect_shards(s, _EchoTransport(), b"id", "rccl") == "rccl" and s.calls == ["comm_init"]
+    with pytest.raises(RuntimeError, match="no exchange"):
+        connect_shards(_ScriptedShard(export=False, comm=False), _EchoTransport(), b"id")
+    with pytest.raises(RuntimeError, match="mailboxes"):
+        connect_shards(_ScriptedShard(selftest=False), _EchoTransport(), b"id", "mailboxes")
+    one = _EchoTransport()
+    one.world = 1
+    assert connect_shards(_ScriptedShard(), one, None) == "none"

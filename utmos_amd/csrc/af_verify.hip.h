@@ -42,9 +42,9 @@ __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c
     hi = h;
 }
 
-__global__ __launch_bounds__(256) void k_cand(PickArgs a)
+__global__ __launch_bounds__(1024) void k_cand(PickArgs a)
 {
-    __shared__ double wmax[4];
+    __shared__ double wmax[16];
     __shared__ unsigned n_c;
     __shared__ int inexact, any_inexact, zero_est;
     IterState *st = a.st;
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
     const unsigned n_active = st->n_active;
     if (threadIdx.x == 0) { n_c = 0; inexact = 0; any_inexact = 0; zero_est = 0; }
     double best_lo = -__builtin_inf();
-    for (unsigned i = threadIdx.x; i < n_active; i += 256) {
+    for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
         const unsigned s = a.act[i];
         double lo, hi, est;
         bool exact;
@@ -66,8 +66,9 @@ __global__ __launch_bounds__(256) void k_cand(PickArgs a)
     }
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best_lo;
     __syncthreads();
-    best_lo = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
-    for (unsigned i = threadIdx.x; i < n_active; i += 256) {
+    best_lo = wmax[0];
+    for (unsigned w = 1; w < (blockDim.x >> 6); ++w) best_lo = fmax(best_lo, wmax[w]);
+    for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
         const unsigned s = a.act[i];
         const u64 c = a.cnt[s];
         double lo, hi, est;

@@ -279,7 +279,7 @@ static i64 iteration_bytes(const utm_ctx *c, u64 a, int kind = -1)
 static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
 {
     if (!a.cand) return;
-    hipLaunchKernelGGL(k_cand, dim3(1), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_cand, dim3(1), dim3(c->active_ub > 512 ? 1024 : 256), 0, c->stream, a);
     const unsigned seq_blocks = (std::max(1u, c->active_ub) + 1023) / 1024;  // (only busy when the candidate list overflowed)
     const ChainFast &cf = c->chain_fast;
     if (c->af_mode == UTM_AF_F32) {
