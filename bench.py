@@ -38,6 +38,8 @@ WORKLOADS = {
     "cfg1": ("1.1M x 2,504 (chr22-sized), select all", dict(n_var=1_103_547, n_samp=2504, select=-1)),
     "cfg2": ("10M x 2,504, select all", dict(n_var=10_000_000, n_samp=2504, select=-1)),
     "cfg3": ("10M x 2,504 with float32 AF weighting, select all", dict(n_var=10_000_000, n_samp=2504, select=-1, af=True)),
+    "af64": ("10M x 2,504 with float64 AF values (the reference's in-memory --af), select all",
+             dict(n_var=10_000_000, n_samp=2504, select=-1, af=True, af_dtype="f64")),
     "cfg4": ("50M x 100,000 over the ranks, first 20 iterations", dict(n_var=50_000_000, n_samp=100_000, select=20)),
     "cfg4rank": ("one rank's share of cfg4 on one GPU: 50M x 12,500, first 20 iterations",
                  dict(n_var=50_000_000, n_samp=12_500, select=20)),

@@ -30,7 +30,8 @@
  *   UTM_TARGET_WGS (32768)    workgroups a scoring launch aims for          UTM_MIN_WGS (128), UTM_MIN_WGS_BIG (8192)
  *   UTM_TILE_STEPS (auto)     force the covered tile to 32/16/8/4/2 KiB     smallest grids the 8 KiB / 32 KiB tiles are used for
  *   UTM_NT_LOADS (auto)       non-temporal column loads on/off              UTM_NT_MIN_MB (512) matrix size from which they are used
- *   UTM_FUSE_PICK (1)         pick inside the scoring launch (one shard, integer scores)
+ *   UTM_FUSE_PICK (1)         pick inside the scoring launch (one shard or mailbox exchange, integer scores)
+ *   UTM_CHAIN_PICK (1)        AF with candidate chains: pick inside the chain launch (one shard)
  *   UTM_PICK_THREADS (auto)   threads of the stand-alone k_pick             UTM_BATCH (256; AF 64) iterations between host syncs
  *   UTM_AF_STEPS (16), UTM_AF_SWITCH (0.2), UTM_AF_TARGET_WGS (16384)       AF kernels: tile, dense->streaming switch, grid
  *   UTM_DECR_FIRST_BATCH (8), UTM_DECR_INTERLEAVED (1)                      decremental mode: first batch size, second copy on/off

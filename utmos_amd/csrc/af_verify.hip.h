@@ -394,14 +394,50 @@ __device__ __forceinline__ double chain_parallel(const double *__restrict__ vals
 // within the error bound (cand_overflow) -- then every selectable sample is re-scored with the plain sequential
 // chain, one lane per sample (what a k_score_seq launch of its own did, at a launch per iteration).
 template <typename AF_T>
+__device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks, int n_chunks, const IterState *__restrict__ st,
+                                            CandBuf *__restrict__ cand, const ChainFast &f, const unsigned *__restrict__ act,
+                                            u64 *__restrict__ cnt, double *__restrict__ fscore);
+
+// PICK: the iteration's pick (k_pick<0>'s body) runs in whichever workgroup of this launch finishes last -- one launch
+// less per iteration wherever candidates are verified (float64 AF: every iteration).  Arrival is one returning atomic
+// per workgroup (67-odd of them); chain results are published with agent-scope stores and read back the same way.
+template <typename AF_T, bool PICK>
 __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chunks, int n_chunks,
                                                 const IterState *__restrict__ st, CandBuf *__restrict__ cand, ChainFast f,
-                                                const unsigned *__restrict__ act, u64 *__restrict__ cnt, double *__restrict__ fscore)
+                                                const unsigned *__restrict__ act, u64 *__restrict__ cnt, double *__restrict__ fscore,
+                                                const PickArgs pa, unsigned *__restrict__ arrivals)
+{
+    if (st->done) return;  // (uniform over the launch: nobody arrives, nobody picks)
+    chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore);
+    if (PICK) {
+        __shared__ int last;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // this workgroup's results (cand->val by an agent-scope store; the overflow blocks' scores by plain stores
+            // behind a fence) are out before it arrives
+            if (blockIdx.x >= UTM_MAX_CAND) __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = t == gridDim.x - 1;
+            if (last) __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (last) {
+            if (st->need_chain && st->cand_overflow) __threadfence();  // (rare: every sample was re-scored by other workgroups)
+            pick_body<0, true>(pa);
+        }
+    }
+}
+
+template <typename AF_T>
+__device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks, int n_chunks, const IterState *__restrict__ st,
+                                            CandBuf *__restrict__ cand, const ChainFast &f, const unsigned *__restrict__ act,
+                                            u64 *__restrict__ cnt, double *__restrict__ fscore)
 {
     __shared__ double buf[UTM_CHAIN_CAP];
     __shared__ unsigned wtot[2][16];  // double buffered: one barrier per empty round
     __shared__ int dense;
-    if (st->done || !st->need_chain) return;
+    if (!st->need_chain) return;
     if (blockIdx.x >= UTM_MAX_CAND) {
         const unsigned i = (blockIdx.x - UTM_MAX_CAND) * 1024 + threadIdx.x;
         if (st->cand_overflow && i < st->n_active) seq_score_sample<AF_T>(chunks, n_chunks, act[i], cnt, fscore);
@@ -441,7 +477,7 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
             }
             __syncthreads();
             const double sum = chain_parallel(f.vals + (size_t)blockIdx.x * f.n_segs * f.seg_cap, f.seg_cap, offs, f.n_segs, sc);
-            if (tid == 0) cand->val[blockIdx.x] = sum;
+            if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[blockIdx.x]), __builtin_bit_cast(u64, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         __syncthreads();  // (dense: the one-workgroup chain below reuses buf)
@@ -503,5 +539,5 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
             }
         }
     }
-    if (tid == 0) cand->val[blockIdx.x] = acc;
+    if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[blockIdx.x]), __builtin_bit_cast(u64, acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -275,24 +275,32 @@ static i64 iteration_bytes(const utm_ctx *c, u64 a, int kind = -1)
     return b;
 }
 
-// Verified-parallel AF: candidates -> their sequential chains (-> everyone, if too many tie).
-static void enqueue_candidates(utm_ctx *c, const PickArgs &a)
+// Verified-parallel AF: candidates -> their chains (-> everyone, if too many tie) [-> the pick, in the chain launch's
+// last workgroup, when `pick_inside`].  Returns whether the pick was enqueued with it.
+static bool enqueue_candidates(utm_ctx *c, const PickArgs &a, bool pick_inside)
 {
-    if (!a.cand) return;
+    if (!a.cand) return false;
     hipLaunchKernelGGL(k_cand, dim3(1), dim3(c->active_ub > 512 ? 1024 : 256), 0, c->stream, a);
     const unsigned seq_blocks = (std::max(1u, c->active_ub) + 1023) / 1024;  // (only busy when the candidate list overflowed)
     const ChainFast &cf = c->chain_fast;
+    const dim3 grid(UTM_MAX_CAND + seq_blocks);
+    const int n_chunks = (int)c->chunks.size();
+#define UTM_LAUNCH_CHAIN(T, PICK)                                                                                                \
+    hipLaunchKernelGGL((k_chain<T, PICK>), grid, dim3(1024), 0, c->stream, c->d_seq, n_chunks, c->d_st, c->d_cand, cf, c->d_act, \
+                       c->d_cnt, c->d_fscore, a, c->d_arrivals)
     if (c->af_mode == UTM_AF_F32) {
         if (cf.counts)
             hipLaunchKernelGGL(k_chain_fill<float>, dim3(cf.n_segs, cf.n_cand), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
-        hipLaunchKernelGGL(k_chain<float>, dim3(UTM_MAX_CAND + seq_blocks), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                           c->d_cand, cf, c->d_act, c->d_cnt, c->d_fscore);
+        if (pick_inside) UTM_LAUNCH_CHAIN(float, true);
+        else UTM_LAUNCH_CHAIN(float, false);
     } else {
         if (cf.counts)
             hipLaunchKernelGGL(k_chain_fill<double>, dim3(cf.n_segs, cf.n_cand), dim3(1024), 0, c->stream, c->d_seq, c->d_st, c->d_cand, cf);
-        hipLaunchKernelGGL(k_chain<double>, dim3(UTM_MAX_CAND + seq_blocks), dim3(1024), 0, c->stream, c->d_seq, (int)c->chunks.size(), c->d_st,
-                           c->d_cand, cf, c->d_act, c->d_cnt, c->d_fscore);
+        if (pick_inside) UTM_LAUNCH_CHAIN(double, true);
+        else UTM_LAUNCH_CHAIN(double, false);
     }
+#undef UTM_LAUNCH_CHAIN
+    return pick_inside;
 }
 
 static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
@@ -302,7 +310,12 @@ static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
     // 128, 64 threads: 626.8, 623.6, 625.1, 629.6, 641.3 ms per cfg2 run)
     const unsigned pick_threads = pick_env ? (unsigned)pick_env : c->active_ub > 16384 ? 1024 : 512;
     PickArgs a = pick_args(c, decr);
-    enqueue_candidates(c, a);
+    static const int chain_pick = tune_env("UTM_CHAIN_PICK", 1);
+    const bool only_shard = c->n_ranks == 1 && c->n_local == c->n_total && !c->comm;
+    if (enqueue_candidates(c, a, /*pick_inside=*/only_shard && chain_pick)) {
+        HIP_TRY(hipGetLastError());
+        return UTM_OK;  // the chain launch's last workgroup runs k_pick<0>'s body
+    }
     if (c->n_ranks > 1 && c->mbox_ok) {
         // device-side exchange: post this shard's record into every shard's mailbox, wait for theirs, decide
         hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, c->stream, a);  // pick, post, collect, decide

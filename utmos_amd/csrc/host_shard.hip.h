@@ -22,7 +22,7 @@ extern "C" int utm_local_best(utm_ctx *c, utm_record *rec)
     c->keep_valid = false;
     TRY(enqueue_score(c));
     PickArgs a = pick_args(c);
-    enqueue_candidates(c, a);
+    enqueue_candidates(c, a, false);
     hipLaunchKernelGGL(k_pick<1>, dim3(1), dim3(1024), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(rec, c->d_xbuf + (u64)c->rank * UTM_HDR_WORDS, sizeof *rec, hipMemcpyDeviceToHost, c->stream));

@@ -263,8 +263,10 @@ __device__ __forceinline__ void fused_pick(const PickArgs &a, unsigned n_tiles, 
 
 // MODE 0: single shard -- pick and decide.  1: write this shard's record into its exchange slot.
 // 2: as 1, and post the record into every shard's mailbox (device-side exchange over P2P mappings).
-template <int MODE>
-__global__ __launch_bounds__(1024) void k_pick(PickArgs a)
+// COHERENT_VALS: the candidates' chain results were written during THIS launch by other workgroups (the pick riding at
+// the end of k_chain): they are read with agent-scope atomic loads instead of plain ones.
+template <int MODE, bool COHERENT_VALS = false>
+__device__ __forceinline__ void pick_body(const PickArgs &a)
 {
     __shared__ Cand wbest[16];
     __shared__ int late;
@@ -288,7 +290,9 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
         const unsigned n_cand = (unsigned)st->n_cand;
         for (unsigned b = threadIdx.x; b < n_cand; b += blockDim.x) {
             const unsigned s = a.cand->samp[b];
-            double v = a.cand->val[b];
+            double v = COHERENT_VALS ? __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&a.cand->val[b]), __ATOMIC_RELAXED,
+                                                                                    __HIP_MEMORY_SCOPE_AGENT))
+                                     : a.cand->val[b];
             if (a.weights) v *= a.weights[a.first + s];
             const Cand cand{v, (i64)a.first + s, a.cand->cnt[b], a.cand->pos[b]};
             if (better(cand, best)) best = cand;
@@ -344,6 +348,12 @@ __global__ __launch_bounds__(1024) void k_pick(PickArgs a)
         __syncthreads();
         mailbox_exchange_and_decide(a, &late);
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_pick(PickArgs a)
+{
+    pick_body<MODE>(a);
 }
 
 __global__ void k_decide(PickArgs a)

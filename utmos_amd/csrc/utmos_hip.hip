@@ -166,6 +166,7 @@ struct utm_ctx {
     SeqChunk *d_seq = nullptr;      // chunk table of the chain kernels, covered = the chunks' CURRENT buffers
     SeqChunk *d_seq_alt = nullptr;  // ... the same with the other buffer of every pair (swapped together)
     CandBuf *d_cand = nullptr;
+    unsigned *d_arrivals = nullptr;  // workgroups of a k_chain launch that have finished (its last one runs the pick)
     ChainFast chain_fast{nullptr, 0, nullptr, nullptr, 0, 0};  // device buffers of the chains' fast path
     ChainSeg *d_segs = nullptr;
     u64 *d_cnt_keep = nullptr;   // persistent per-sample counts (mirror of the last full scoring, then decremented)
@@ -259,7 +260,7 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
 static const char *const g_env_knobs[] = {
     "UTM_TARGET_WGS", "UTM_MIN_WGS", "UTM_MIN_WGS_BIG", "UTM_TILE_STEPS", "UTM_NT_LOADS", "UTM_NT_MIN_MB", "UTM_FUSE_PICK",
     "UTM_PICK_THREADS", "UTM_BATCH", "UTM_AF_STEPS", "UTM_AF_SWITCH", "UTM_AF_TARGET_WGS", "UTM_DECR_FIRST_BATCH",
-    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER"};
+    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER", "UTM_CHAIN_PICK"};
 static void report_env_once()
 {
     static bool said = false;
@@ -309,6 +310,8 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     HIP_TRY(hipMalloc(&c->d_res_score, ((size_t)n_samp_total + 1) * 8));
     HIP_TRY(hipMalloc(&c->d_xbuf, UTM_HDR_WORDS * 8));
     HIP_TRY(hipMalloc(&c->d_cand, sizeof(CandBuf)));
+    HIP_TRY(hipMalloc(&c->d_arrivals, 128));
+    HIP_TRY(hipMemsetAsync(c->d_arrivals, 0, 128, c->stream));
     HIP_TRY(hipMalloc(&c->d_cnt_keep, (size_t)n_samp_local * 8));
     HIP_TRY(hipMalloc(&c->d_afsum_keep, (size_t)n_samp_local * 8));
     c->decr_enabled = flags & UTM_FLAG_DECREMENTAL;
@@ -345,6 +348,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
         (void)hipFree(ch.mask);
     }
     (void)hipFree(c->d_cand);
+    (void)hipFree(c->d_arrivals);
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
