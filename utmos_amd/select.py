@@ -365,14 +365,14 @@ def parse_args(args):
         logging.error("A matrix store cannot be combined with other input files")
         sys.exit(1)
     if not args.in_files and not args.lowmem:
-        logging.error("No input files provided")
+        logging.error("Nothing to read: give input files, or --lowmem STORE to select from an existing store")
         sys.exit(1)
     if not args.in_files:                        # --lowmem STORE alone: select from the existing store
         args.in_files, args.lowmem = [args.lowmem], 1
     elif stores and not args.lowmem:
         logging.info("Input is a matrix store: reading it directly")
         args.lowmem = 1
-    logging.info("Params:\n%s", json.dumps(vars(args), indent=4))
+    logging.info("options in effect: %s", json.dumps(vars(args), sort_keys=True))
     return args
 
 
@@ -389,7 +389,7 @@ def _gather_var_count(transport, local_counts, n_samples):
 
 def select_main(cmdargs):
     """`utmos select`: load, select, write the TSV (header + one flushed line per selected sample, select.py:440-446)."""
-    global MAXMEM  # pylint: disable=global-statement
+    global MAXMEM
     args = parse_args(cmdargs)
     MAXMEM = args.maxmem
     missing = [path for path in args.in_files if not os.path.exists(path)]
