@@ -73,7 +73,7 @@ def parse():
     p.add_argument("--decremental", action="store_true",
                    help="SURVEY 8f-4 shortcut (exact, reads far fewer bytes): reported separately, never the default")
     p.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip rank 0's single-GPU re-run and comparison")
-    p.add_argument("--exchange", choices=["auto", "mailboxes", "rccl", "both"], default="both",
+    p.add_argument("--exchange", choices=["auto", "mailboxes", "rccl", "rccl-allreduce", "both"], default="both",
                    help="N > 1: both = headline through the default exchange (mailboxes, else RCCL) and the same steps again "
                         "through RCCL (also_exchange); auto / mailboxes / rccl = that one only")
     p.add_argument("--decr-threshold", type=float, default=0.0, help="--decremental: newly-covered word fraction below which an iteration goes decremental (0 = library default)")
@@ -394,7 +394,16 @@ def main():
             also_exchange = {"rccl": {"value": r2["iters"] / r2["elapsed"], "unit": "iterations/s",
                                       "ms_per_step": r2["elapsed"] / max(1, args.steps) * 1e3, "exchange": m.exchange(),
                                       "rccl_ranks": s2["rccl_ranks"], "rows_match_default_exchange": same,
-                                      "protocol": "per iteration: ncclAllGather of 64-byte records, ncclBroadcast of the winner's column from its owner"}}
+                                      "protocol": "per iteration: ncclAllGather of 64-byte records, ncclBroadcast of the winner's column from its owner "
+                                                  "(one host sync per iteration: the root is data dependent)"}}
+            m.comm_column_by_allreduce(True)
+            r3 = timed_steps(m, k_sel, args.steps, min(args.warmup, 1), sync_max)
+            same3 = bool(len(r3["rows"][0]) == len(idx) and (r3["rows"][0] == idx).all() and (r3["rows"][1] == new).all())
+            also_exchange["rccl_allreduce"] = {
+                "value": r3["iters"] / r3["elapsed"], "unit": "iterations/s", "ms_per_step": r3["elapsed"] / max(1, args.steps) * 1e3,
+                "exchange": m.exchange(), "rccl_ranks": r3["stats"]["rccl_ranks"], "rows_match_default_exchange": same3,
+                "protocol": "per iteration: ncclAllGather of 64-byte records, ncclAllReduce(sum) of owner's-column-else-zeros (root-free, no host sync)"}
+            m.comm_column_by_allreduce(False)
         else:
             also_exchange = {"rccl": {"error": f"RCCL communicator unavailable on some rank ({err})"}}
         m.p2p_use_mailboxes(True)             # back to the headline's exchange for the check below

@@ -102,6 +102,7 @@ typedef struct utm_stats {
 #define UTM_EXCHANGE_MAILBOX 1 /* 64-byte records through hipIpc-mapped device mailboxes; winner column read from a peer mapping / local copy */
 #define UTM_EXCHANGE_RCCL 2    /* ncclAllGather of the records, then ncclBroadcast of the winner's column from its owner */
 #define UTM_EXCHANGE_CALLER 3  /* a shard without a device-side exchange: the caller drives utm_local_best / utm_apply_records */
+#define UTM_EXCHANGE_RCCL_SUM 4 /* RCCL, root-free: ncclAllGather of the records, then ncclAllReduce(sum) of a buffer that holds the winner's column on its owner and zeros elsewhere (utm_comm_column_by_allreduce) */
 
 const char *utm_last_error(void);
 int utm_abi_version(void);
@@ -224,6 +225,12 @@ int utm_comm_get_unique_id(void *id);
  * (state 0) on another rank are broadcast by their owner at utm_reset. */
 int utm_comm_init(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *id);
 int utm_comm_allreduce_max(utm_ctx *ctx, double *value); /* in place; also a barrier */
+/* How the winner's column travels in the RCCL exchange.  0 (default): ncclBroadcast from its owner -- the root is
+ * data dependent, so the host reads it after every iteration (one stream sync per iteration).  1: the owner puts the
+ * column into the winner-column buffer, everybody else zeros, and one ncclAllReduce(sum, uint64) leaves the column
+ * on every rank -- about twice the bytes on the links, but no root and therefore no host in the loop (iterations are
+ * enqueued in batches like on one GPU).  Same rows either way. */
+int utm_comm_column_by_allreduce(utm_ctx *ctx, int32_t on);
 
 #ifdef __cplusplus
 }

@@ -218,7 +218,8 @@ def test_bench_multi_rank_launch_contract_on_one_gpu(tmp_path):
     assert line["sharded_rows_match_single_gpu"] is True
     assert line["exchange"] == "mailboxes" and line["p2p_replica_bytes"] > 0 and line["rccl_ranks"] is None
     rccl = line["also_exchange"]["rccl"]
-    assert "error" in rccl or (rccl["rccl_ranks"] == 3 and rccl["rows_match_default_exchange"] is True)
+    assert "error" in rccl or (rccl["rccl_ranks"] == 3 and rccl["rows_match_default_exchange"] is True
+                               and line["also_exchange"]["rccl_allreduce"]["rows_match_default_exchange"] is True)
     assert line["config"]["iterations_per_step"] == 301 and line["also"] is None
 
 

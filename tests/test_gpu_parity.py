@@ -352,8 +352,9 @@ def test_sharded_building_blocks_two_shards_one_gpu(dev):
     assert got_idx == exp[0].tolist() and got_new == exp[1].tolist() and got_score == exp[2].tolist()
 
 
+@pytest.mark.parametrize("column", ["broadcast", "allreduce"])
 @pytest.mark.parametrize("mode", ["int", "weights", "af32", "af64", "chunks", "used"])
-def test_rccl_exchange_single_rank(dev, mode, monkeypatch):
+def test_rccl_exchange_single_rank(dev, mode, column, monkeypatch):
     """north_star's RCCL protocol -- ncclAllGather of the records, k_decide, ncclBroadcast of the winner's column from
     its owner -- with a 1-rank communicator (RCCL refuses two ranks on this box's one GPU).  UTM_TEST_REMOTE_WINNER
     makes the context read every winner from the broadcast buffer, as a non-owner rank would, so the whole data path
@@ -384,11 +385,13 @@ def test_rccl_exchange_single_rank(dev, mode, monkeypatch):
     with m:
         m.comm_init(0, 1, dev.DeviceMatrix.comm_unique_id())
         assert m.allreduce_max(3.5) == 3.5
+        if column == "allreduce":       # root-free variant: the column by ncclAllReduce(sum) of owner's-column-else-zeros
+            m.comm_column_by_allreduce(True)
         m.set_state(state)
         m.set_weights(w)
         got = m.run(n_samp)
         st = m.stats()
-        assert m.exchange() == "rccl" and st["rccl_ranks"] == 1
+        assert m.exchange() == ("rccl" if column == "broadcast" else "rccl-allreduce") and st["rccl_ranks"] == 1
     assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
 
 

@@ -37,7 +37,7 @@ class Stats(ctypes.Structure):
                 ("exchange", ctypes.c_int32), ("rccl_ranks", ctypes.c_int32)]
 
 
-EXCHANGE_NAMES = {0: "none", 1: "mailboxes", 2: "rccl", 3: "caller-driven"}
+EXCHANGE_NAMES = {0: "none", 1: "mailboxes", 2: "rccl", 3: "caller-driven", 4: "rccl-allreduce"}
 
 
 _P = ctypes.c_void_p
@@ -82,6 +82,7 @@ PROTOTYPES = {
     "utm_comm_get_unique_id": [_P],
     "utm_comm_init": [_P, _I32, _I32, _P],
     "utm_comm_allreduce_max": [_P, ctypes.POINTER(ctypes.c_double)],
+    "utm_comm_column_by_allreduce": [_P, _I32],
 }
 
 _lib = None

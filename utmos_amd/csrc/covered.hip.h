@@ -37,3 +37,20 @@ __global__ __launch_bounds__(256) void k_or_column_remote(u64 *__restrict__ cove
     for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256)
         covered[w] |= __hip_atomic_load(&col[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+
+// RCCL exchange, root-free form: the winner's column on its owner, zeros everywhere else -- the sum over the ranks
+// is then the column.  All chunks of the winner-column buffer in one launch (grid.y = chunk).
+struct StageChunk {
+    const u64 *cols;
+    u64 wp, off;
+};
+__global__ __launch_bounds__(256) void k_stage_winner(u64 *__restrict__ wincol, const StageChunk *__restrict__ chunks,
+                                                      const IterState *__restrict__ st, int rank, unsigned first)
+{
+    if (st->done || !st->prev_valid) return;
+    const StageChunk ch = chunks[blockIdx.y];
+    const bool mine = st->prev_rank == rank;
+    const u64 *col = mine ? ch.cols + (u64)(st->prev_gidx - (i64)first) * ch.wp : nullptr;
+    u64 *dst = wincol + ch.off;
+    for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < ch.wp; w += (u64)gridDim.x * 256) dst[w] = mine ? col[w] : 0ull;
+}

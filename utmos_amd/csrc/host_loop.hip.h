@@ -327,6 +327,15 @@ static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
         HIP_TRY(hipGetLastError());
         NCCL_TRY(g_rccl.AllGather(c->d_xbuf + (u64)c->rank * UTM_HDR_WORDS, c->d_xbuf, UTM_HDR_WORDS, ncclUint64, c->comm, c->stream));
         hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, c->stream, a);
+        if (c->column_by_allreduce) {
+            // root-free second half: the owner stages its winner's column, everybody else zeros, the sum is the column
+            u64 max_wp = 0;
+            for (auto &ch : c->chunks) max_wp = std::max(max_wp, ch.wp);
+            hipLaunchKernelGGL(k_stage_winner, dim3((unsigned)std::min<u64>(256, (max_wp + 255) / 256), (unsigned)c->chunks.size()), dim3(256), 0,
+                               c->stream, c->d_wincol, c->d_stage, (const IterState *)c->d_st, c->rank, c->first);
+            HIP_TRY(hipGetLastError());
+            NCCL_TRY(g_rccl.AllReduce(c->d_wincol, c->d_wincol, c->col_words, ncclUint64, ncclSum, c->comm, c->stream));
+        }
     } else if (c->n_ranks == 1 && c->n_local == c->n_total) {
         hipLaunchKernelGGL(k_pick<0>, dim3(1), dim3(pick_threads), 0, c->stream, a);
     } else {
@@ -380,7 +389,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     static const int batch_env = tune_env("UTM_BATCH", 0);
     static const int decr_first = std::max(1, tune_env("UTM_DECR_FIRST_BATCH", 8));
     // (RCCL exchange: one iteration per sync -- the column broadcast's root is only known on the host after it)
-    const int batch = rccl_exchange(c) ? 1 : batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
+    const int batch = rccl_needs_root(c) ? 1 : batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
     i64 enq = 0;
     while (enq < k_max && !c->finished) {
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
@@ -414,7 +423,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         enq += n;
         const i64 before = c->iter;
         TRY(sync_state(c));
-        if (rccl_exchange(c) && c->iter > before && !c->finished) {
+        if (rccl_needs_root(c) && c->iter > before && !c->finished) {
             // second half of the RCCL exchange: the winner's column from its owner into every shard's winner-column
             // buffer, where the next scoring pass ORs it into covered (select.py:100 on every replica)
             const int owner = c->h_st->prev_rank;
@@ -568,7 +577,7 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->p2p_replica_bytes = (i64)c->replica_bytes;
     out->exchange = c->n_local == c->n_total && !c->comm ? UTM_EXCHANGE_NONE
                     : (c->n_ranks > 1 && c->mbox_ok)     ? UTM_EXCHANGE_MAILBOX
-                    : c->comm                            ? UTM_EXCHANGE_RCCL
+                    : c->comm                            ? (c->column_by_allreduce ? UTM_EXCHANGE_RCCL_SUM : UTM_EXCHANGE_RCCL)
                                                          : UTM_EXCHANGE_CALLER;
     out->rccl_ranks = 0;
     if (c->comm) {

@@ -357,6 +357,21 @@ extern "C" int utm_comm_init(utm_ctx *c, int32_t rank, int32_t n_ranks, const vo
     return UTM_OK;
 }
 
+extern "C" int utm_comm_column_by_allreduce(utm_ctx *c, int32_t on)
+{
+    CTX(c);
+    if (!c->comm) return fail(UTM_ESTATE, "no communicator (utm_comm_init)");
+    if (on && !c->d_stage) {
+        std::vector<StageChunk> table;
+        for (auto &ch : c->chunks) table.push_back(StageChunk{ch.cols, ch.wp, ch.off});
+        HIP_TRY(hipMalloc(&c->d_stage, table.size() * sizeof(StageChunk)));
+        HIP_TRY(copy_sync(c, c->d_stage, table.data(), table.size() * sizeof(StageChunk), hipMemcpyHostToDevice));
+    }
+    c->column_by_allreduce = on != 0;
+    c->prepared = false;
+    return UTM_OK;
+}
+
 extern "C" int utm_comm_allreduce_max(utm_ctx *c, double *value)
 {
     CTX(c);

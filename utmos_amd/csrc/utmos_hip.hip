@@ -162,6 +162,7 @@ struct utm_ctx {
     u64 *d_wincol = nullptr;  // a remote winner's whole column (col_words) as the exchange delivered it: the
                               // ncclBroadcast from its owner, or utm_apply_records' winner_col
     u64 wincol_words = 0;
+    StageChunk *d_stage = nullptr;  // chunk table of k_stage_winner (root-free RCCL column exchange)
     bool remote_winner_test = false;  // UTM_TEST_REMOTE_WINNER=1 (tests): read a local winner from d_wincol too
     SeqChunk *d_seq = nullptr;      // chunk table of the chain kernels, covered = the chunks' CURRENT buffers
     SeqChunk *d_seq_alt = nullptr;  // ... the same with the other buffer of every pair (swapped together)
@@ -207,6 +208,7 @@ struct utm_ctx {
     // RCCL
     int rank = 0, n_ranks = 1;
     ncclComm_t comm = nullptr;
+    bool column_by_allreduce = false;  // RCCL exchange: winner column by a root-free all-reduce instead of a broadcast
     std::vector<unsigned> rank_first, rank_local;  // every shard's sample range (utm_comm_init / utm_p2p_import)
     // P2P: every rank maps every other rank's columns (hipIpc); the winner's column is then read in place
     bool p2p = false;
@@ -240,6 +242,8 @@ static inline u64 round_up(u64 x, u64 m) { return (x + m - 1) / m * m; }
 // The per-iteration exchange runs through RCCL (records all-gathered, winner column broadcast) rather than through
 // the device mailboxes; a communicator next to working mailboxes is not used by the loop.
 static bool rccl_exchange(const utm_ctx *c) { return c->comm && !(c->n_ranks > 1 && c->mbox_ok); }
+// ... in its broadcast form: the host has to learn the winner's rank after every iteration
+static bool rccl_needs_root(const utm_ctx *c) { return rccl_exchange(c) && !c->column_by_allreduce; }
 // Remote winners are read in place through the hipIpc mappings (not from a local copy / the broadcast buffer).
 static bool remote_reads(const utm_ctx *c) { return c->p2p && !c->replicated && !rccl_exchange(c); }
 
@@ -353,7 +357,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
-    (void)hipFree(c->d_xbuf); (void)hipFree(c->d_wincol); (void)hipFree(c->d_seq); (void)hipFree(c->d_seq_alt); (void)hipFree(c->d_varcount);
+    (void)hipFree(c->d_xbuf); (void)hipFree(c->d_wincol); (void)hipFree(c->d_stage); (void)hipFree(c->d_seq); (void)hipFree(c->d_seq_alt); (void)hipFree(c->d_varcount);
     if (c->h_st) (void)hipHostFree(c->h_st);
     for (auto e : c->ev) (void)hipEventDestroy(e);
     if (c->ev_loop0) (void)hipEventDestroy(c->ev_loop0);

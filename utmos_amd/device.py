@@ -237,9 +237,26 @@ class DeviceMatrix:
         """One RCCL communicator over the shards.  Unless the mailboxes are switched on, run() then exchanges through
         it: ncclAllGather of the records, ncclBroadcast of the winner's column from its owner."""
         buf = ctypes.create_string_buffer(bytes(unique_id), nat.UNIQUE_ID_BYTES)
-        nat.check(nat.lib().utm_comm_init(self._h, int(rank), int(n_ranks), buf))
+        # RCCL announces itself ("RCCL version : ...") on stdout when its first communicator comes up; stdout belongs to
+        # the caller (the TSV of `select`, bench.py's one JSON line): that banner goes to stderr instead
+        import os
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            code = nat.lib().utm_comm_init(self._h, int(rank), int(n_ranks), buf)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        nat.check(code)
         self.fused = True
         self.has_comm = True
+
+    def comm_column_by_allreduce(self, on=True):
+        """RCCL exchange: winner column by a root-free ncclAllReduce(sum) instead of an ncclBroadcast from its owner
+        (no host sync per iteration; about twice the bytes on the links).  Same rows."""
+        nat.check(nat.lib().utm_comm_column_by_allreduce(self._h, 1 if on else 0))
 
     def allreduce_max(self, value):
         v = ctypes.c_double(float(value))

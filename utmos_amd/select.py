@@ -348,7 +348,7 @@ def _build_parser():
     gpu.add_argument("--brute-force", action="store_true",
                      help="re-score every sample from scratch in every iteration (default: later iterations only "
                           "subtract what the last winner newly captured; identical output)")
-    gpu.add_argument("--exchange", choices=["auto", "mailboxes", "rccl"], default="auto",
+    gpu.add_argument("--exchange", choices=["auto", "mailboxes", "rccl", "rccl-allreduce"], default="auto",
                      help="several processes: how the shards meet every iteration [auto: device mailboxes, else RCCL]")
     return parser
 

@@ -11,7 +11,9 @@ utmos/select.py:48) -> the winner's column reaches every rank -> covered |= colu
              loop runs on the devices alone -- 64-byte records stored straight into the peers' mailboxes, the winner's
              column read from a one-time local copy of the peers' columns (when HBM allows) or in place over xGMI;
   rccl       one ncclAllGather of the records and one ncclBroadcast of the winner's column from its owner per
-             iteration (north_star's protocol; also what `--exchange rccl` forces);
+             iteration (north_star's protocol; also what `--exchange rccl` forces); `rccl-allreduce` is its root-free
+             variant: the column travels by an ncclAllReduce(sum) of owner's-column-else-zeros, so no host sync is
+             needed to learn the root;
   otherwise  an error: there is no host-staged product path.
 
 `sharded_greedy` drives the same protocol from the host through the C ABI's building blocks (utm_local_best /
@@ -290,8 +292,8 @@ def enable_mailboxes(shard, transport):
 
 
 def connect_shards(shard, transport, uid, exchange="auto"):
-    """Make shard.run() collective.  exchange: 'auto' (mailboxes, else RCCL), 'mailboxes', 'rccl'.  Returns the name
-    of the exchange in effect; raises RuntimeError when none can be set up on every rank."""
+    """Make shard.run() collective.  exchange: 'auto' (mailboxes, else RCCL), 'mailboxes', 'rccl', 'rccl-allreduce'.
+    Returns the name of the exchange in effect; raises RuntimeError when none can be set up on every rank."""
     if transport.world == 1:
         return "none"
     if exchange in ("auto", "mailboxes") and enable_mailboxes(shard, transport):
@@ -305,6 +307,9 @@ def connect_shards(shard, transport, uid, exchange="auto"):
         err = exc
     if not transport.agree(err is None):
         raise RuntimeError(f"no exchange between the shards: hipIpc mailboxes unavailable and RCCL did not come up ({err})")
+    if exchange == "rccl-allreduce":
+        shard.comm_column_by_allreduce(True)
+        return "rccl-allreduce"
     return "rccl"
 
 
