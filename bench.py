@@ -339,6 +339,9 @@ def main():
     elif args.force_comm:
         m.comm_init(0, 1, device.DeviceMatrix.comm_unique_id())
         exchange = "rccl"
+        if args.exchange == "rccl-allreduce":
+            m.comm_column_by_allreduce(True)
+            exchange = "rccl-allreduce"
 
     def sync_max(value):
         """Barrier + maximum over the ranks (host side: the ranks' loops are already drained)."""
@@ -474,7 +477,7 @@ def main():
                    "iterations_per_step": head["iterations_per_step"], "tot_captured": head["tot_captured"], "chunks": head["chunks"],
                    "seed": args.seed, "sharding": f"sample axis over {world} GPU(s)" if world > 1 else "none",
                    "generator_s": head["generator_s"], "af_verified_parallel": st["af_fixed_point"] if args.af else None},
-        "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": final_stats["rccl_ranks"] if exchange == "rccl" else None,
+        "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": final_stats["rccl_ranks"] if exchange.startswith("rccl") else None,
         "p2p_replica_bytes": final_stats["p2p_replica_bytes"] if world > 1 else None,
         "also_exchange": also_exchange,
         "scoring": "decremental after the first passes (bytes = what this variant actually reads; NOT the brute-force "

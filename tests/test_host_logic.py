@@ -361,6 +361,9 @@ class _ScriptedShard:
         if not self.script["comm"]:
             raise RuntimeError("RCCL refused")
 
+    def comm_column_by_allreduce(self, on):
+        self.calls.append(f"allreduce={on}")
+
 
 def test_connect_shards_order_mailboxes_then_rccl_then_error():
     """sharded.connect_shards: mailboxes when every step works on every rank, else RCCL, else an error -- there is no
@@ -370,7 +373,8 @@ def test_connect_shards_order_mailboxes_then_rccl_then_error():
     assert connect_shards(s, _EchoTransport(), b"id") == "mailboxes" and s.calls == ["export", "import", "selftest", "mailboxes=True"]
     for broken in ("export", "imp", "selftest"):
         s = _ScriptedShard(**{broken: False})
-        assert connect_shards(s, _EchoTransport(), b"id") == "rccl" and s.calls[-1] == "comm_init" and "mailboxes=True" not in s.calls
+        assert connect_shards(s, _EchoTransport(), b"id") == "rccl-allreduce" and s.calls[-2:] == ["comm_init", "allreduce=True"]
+        assert "mailboxes=True" not in s.calls
     s = _ScriptedShard()
     assert connect_shards(s, _EchoTransport(), b"id", "rccl") == "rccl" and s.calls == ["comm_init"]
     with pytest.raises(RuntimeError, match="no exchange"):
