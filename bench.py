@@ -362,7 +362,7 @@ def main():
         # steps through RCCL instead, and the line says so
         if exchange != "mailboxes":
             raise SystemExit(f"bench.py rank {rank}: the {exchange} exchange failed ({failed})")
-        exchange_note = f"the device mailboxes passed their self-test but failed in the loop ({failed}); measured through RCCL instead"
+        exchange_note = f"the device mailboxes passed their self-test but failed in the loop ({failed}); measured through RCCL (root-free form) instead"
         m.p2p_use_mailboxes(False)
         err = None
         try:
@@ -371,8 +371,9 @@ def main():
             err = exc
         if not transport.agree(err is None):
             raise SystemExit(f"bench.py rank {rank}: no working exchange (mailboxes: {failed}; RCCL: {err})")
-        exchange = "rccl"
-        args.exchange = "rccl"
+        m.comm_column_by_allreduce(True)
+        exchange = "rccl-allreduce"
+        args.exchange = "rccl-allreduce"
         res = timed_steps(m, k_sel, args.steps, args.warmup, sync_max)
     st = res["stats"]
     idx, new, _ = res["rows"]
