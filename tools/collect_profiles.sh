@@ -25,7 +25,12 @@ for cfg in cfg2 cfg3 cfg1; do
 done
 echo "== float64 AF (the reference's in-memory --af values)"
 python3 $R/bench.py --af --af-dtype f64 --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_bench.json 2>/dev/null
+python3 $R/bench.py --workload af64 --af-estimate-scores --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_cli_mode_bench.json 2>/dev/null
+echo "== RCCL protocol overhead with a 1-rank communicator (collectives degenerate; launch and sync costs real)"
+for x in rccl rccl-allreduce; do
+  python3 $R/bench.py --force-comm --exchange $x --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off --no-sharded-check > $out/${tag}_cfg2_one_rank_${x}_bench.json 2>/dev/null
+done
 echo "== decremental (optional mode, reported separately)"
 python3 $R/bench.py --decremental --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_cfg2_decremental_bench.json 2>/dev/null
-cp $R/profiles/${tag}_* $out/ 2>/dev/null
+cp $R/profiles/${tag}_*_kernel_stats.csv $R/profiles/${tag}_*_pmc_hbm.json $out/ 2>/dev/null   # (written there by summarize_profile.py just now)
 ls -la $out
