@@ -181,7 +181,7 @@ def micro(seed, n_var, n_samp, with_dups=False, zero_af_rows=0, blank_rows=0):
     af = np.maximum(ac, 1) / (2.0 * n_samp)
     if zero_af_rows:    # informative rows whose AF is 0.0: all-zero rows of the float matrix
         af[rng.choice(n_var, zero_af_rows, replace=False)] = 0.0
-    names = [f"S{i:03d}" for i in range(n_samp)]
+    names = [f"S{i:03d}" for i in range(n_samp)] if n_samp <= 1000 else [f"S{i:04d}" for i in range(n_samp)]
     return part_from_dense(dense, af, names)
 
 
@@ -286,6 +286,14 @@ def main():
         tsv, tr = run_direct(sel, tmp, [m_u], True, False, 12, state=state, weights=wv, full_vectors=True)
         save("initial_used_af64_weights", {"kind": "direct", "parts": [part_json(m_u)], "af": True, "af_dtype": "f64",
              "count": 12, "state": state.tolist(), "weight_vector_hex": [float(x).hex() for x in wv], "tsv": tsv, **tr})
+
+        # ---- 4b. a matrix wide enough for several waves / picker rounds on the device (1,500 samples), select all
+        m_mid = micro(61, 4000, 1500)    # (kept as a compressed fixture of its own, like the chunk re-encodings: tests/golden/mid.npz)
+        np.savez_compressed(os.path.join(GOLD, "mid.npz"), GT=m_mid["GT"], AF=m_mid["AF"].reshape(-1),
+                            samples=np.asarray([x.decode() for x in m_mid["samples"]], dtype="U"))
+        for label, argv in (("mid_int", ["-c", "-1"]), ("mid_af", ["-c", "-1", "--af"])):
+            tsv, tr = run_cli(sel, tmp, [m_mid], argv)
+            save(label, {"kind": "cli", "inputs": ["mid"], "argv": argv, "tsv": tsv, **tr})
 
         # ---- 5. --count resolution as run_selection applies it (select.py:157-159)
         table = []
