@@ -64,7 +64,7 @@ def parse():
     p.add_argument("--chunk-vars", type=int, default=0, help="split the variant axis into chunks of this many variants")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-vars", type=int, default=1_000_000, help="rows of the CPU baseline's sample when full N is not timed")
-    p.add_argument("--cpu-budget-s", type=float, default=40.0,
+    p.add_argument("--cpu-budget-s", type=float, default=75.0,
                    help="CPU seconds the reference port may take; one iteration at full N is timed when it fits here and in host RAM")
     p.add_argument("--no-roofline-pass", action="store_true")
     p.add_argument("--no-also", action="store_true", help="N = 1: skip the other BASELINE configurations after the headline")
@@ -219,7 +219,8 @@ def mem_available_gb():
 def cpu_baseline(args, device_mod, gpu_winners):
     """The reference's algorithm on the host cores (rank 0, N = 1): oracle.score_rowloop = the per-row numpy loop of
     utmos/select.py:33-48, one thread.  BASELINE.md 4 asks for full N when host RAM allows the unpacked bool matrix; one
-    full-N iteration costs ~95 s, so it is timed only when that fits --cpu-budget-s too -- otherwise the first
+    full-N iteration costs 40-95 s depending on the host (calibrated on a 200k-row slice first), so it is timed only
+    when that fits --cpu-budget-s too -- otherwise the first
     `cpu_sample_vars` variants of the same matrix: the first 3 iterations (nothing captured yet: the most expensive
     ones) and one iteration from the state the GPU run had reached after S/2 selections (captured rows are skipped
     there); rates scaled to the full variant count (time per iteration is linear in rows).
@@ -228,13 +229,25 @@ def cpu_baseline(args, device_mod, gpu_winners):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_util as ou
     ram_gb = mem_available_gb()
-    full_bytes_gb = args.n_var * args.n_samp / 1e9 * 1.25        # bool matrix + the packed columns it is unpacked from
-    full_est_s = args.n_var * 9.5e-6                             # 9-10 us per row measured with the reference itself
+    full_bytes_gb = args.n_var * args.n_samp / 1e9 * 2.1         # bool matrix + the unpacked bits it is transposed from
+    # per-row cost of the reference's loop on THIS host: 9-10 us measured with the reference itself in the build
+    # container, ~4 us on the GPU boxes' hosts -- so calibrate on a slice before deciding
+    n_cal = min(args.n_var, 200_000)
+    with device_mod.DeviceMatrix(args.n_samp, device=0) as m:
+        c = m.add_chunk(n_cal)
+        m.synth_fill(c, seed=args.seed)
+        cal = m.download_columns(c)
+    cal = np.ascontiguousarray(np.unpackbits(cal.view(np.uint8), axis=1, bitorder="little")[:, :n_cal].T).astype(bool)
+    t0 = time.perf_counter()
+    ou.npo.score_rowloop(cal, np.ones(args.n_samp, np.uint8))
+    per_row = (time.perf_counter() - t0) / n_cal
+    del cal
+    full_est_s = args.n_var * per_row
     full_n = ram_gb > full_bytes_gb + 8 and full_est_s * 1.3 < args.cpu_budget_s
     n_var = args.n_var if full_n else min(args.cpu_sample_vars, args.n_var)
     why = ("full N" if full_n else
            f"sample: full N needs {full_bytes_gb:.0f} GB of host RAM ({ram_gb:.0f} GB available) and ~{full_est_s:.0f} s per "
-           f"iteration (budget {args.cpu_budget_s:.0f} s)")
+           f"iteration on this host ({per_row * 1e6:.1f} us/row calibrated; budget {args.cpu_budget_s:.0f} s)")
     with device_mod.DeviceMatrix(args.n_samp, device=0) as m:
         c = m.add_chunk(n_var)
         m.synth_fill(c, seed=args.seed)
@@ -253,8 +266,11 @@ def cpu_baseline(args, device_mod, gpu_winners):
     port = {"value": iters / dt * scale, "unit": "iterations/s", "cores": 1, "kind": "port",
             "sample": f"first {iters} greedy iteration(s) on {'all' if full_n else 'the first'} {n_var} of {args.n_var} synthetic "
                       f"variants x {args.n_samp} samples (numpy row loop, {dt:.1f} s); rate scaled by {scale:.4g} to the full variant count",
-            "rows_timed": n_var, "full_n": bool(full_n), "why": why, "host_cpus": os.cpu_count(), "host_mem_available_gb": round(ram_gb, 1)}
-    if not full_n and gpu_winners is not None and len(gpu_winners) >= 2:
+            "rows_timed": n_var, "full_n": bool(full_n), "why": why, "us_per_row_calibrated": round(per_row * 1e6, 2),
+            "host_cpus": os.cpu_count(), "host_mem_available_gb": round(ram_gb, 1)}
+    # a later iteration skips the rows already captured, so it is cheaper than the first: time one from the state the
+    # GPU run had reached after S/2 selections (at full N only when the budget still has room for it)
+    if gpu_winners is not None and len(gpu_winners) >= 2 and (not full_n or dt * 1.6 < args.cpu_budget_s):
         half = len(gpu_winners) // 2
         mid = np.ones(args.n_samp, np.uint8)
         mid[np.asarray(gpu_winners[:half])] = 0          # the GPU run's first S/2 winners are "used": their variants are covered
