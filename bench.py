@@ -299,6 +299,7 @@ def summarize(spec, label, world, steps, res, roofline, t_gen):
             "algo_bytes_per_step": st["algo_bytes"] * world, "hbm_gbps_whole_loop": gbps,
             "hbm_frac_whole_loop": gbps / (HBM_PEAK_GBPS * world), "device_loop_ms_per_step": res["loop_ms"] / max(1, steps),
             "generator_s": round(t_gen, 3),
+            **({k: st[k] for k in ("af_chained_iterations", "af_deferred_rows")} if spec["af"] else {}),  # (of the last step)
             "roofline": None if roofline is None else {k: roofline[k] for k in ("frac", "achieved", "kernel", "launches", "avg_launch_us",
                                                                                "algo_bytes_per_launch")}}
 
@@ -493,7 +494,8 @@ def main():
         "config": {"workload": head["workload"], "n_var": args.n_var, "n_samp": n_total,
                    "iterations_per_step": head["iterations_per_step"], "tot_captured": head["tot_captured"], "chunks": head["chunks"],
                    "seed": args.seed, "sharding": f"sample axis over {world} GPU(s)" if world > 1 else "none",
-                   "generator_s": head["generator_s"], "af_verified_parallel": st["af_fixed_point"] if args.af else None},
+                   "generator_s": head["generator_s"], "af_verified_parallel": st["af_fixed_point"] if args.af else None,
+                   **{k: head[k] for k in ("af_chained_iterations", "af_deferred_rows") if k in head}},
         "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": final_stats["rccl_ranks"] if exchange.startswith("rccl") else None,
         "p2p_replica_bytes": final_stats["p2p_replica_bytes"] if world > 1 else None,
         "also_exchange": also_exchange,

@@ -95,6 +95,9 @@ typedef struct utm_stats {
     int64_t decr_interleaved_bytes; /* HBM held by the word-interleaved copy the decremental iterations stream (0: gather form) */
     int32_t exchange;        /* UTM_EXCHANGE_*: how utm_run's iterations meet the other shards */
     int32_t rccl_ranks;      /* ncclCommCount of the context's communicator, 0 without one */
+    /* allele-frequency scoring, verified-parallel form, since the last utm_reset: */
+    int64_t af_chained_iterations; /* iterations whose pick needed sequential float64 chains on the spot (near-ties) */
+    int64_t af_deferred_rows;      /* rows whose exact float64 score was finished after their batch (one launch set per batch) */
 } utm_stats;
 
 /* utm_stats.exchange */

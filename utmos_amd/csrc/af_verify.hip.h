@@ -42,11 +42,13 @@ __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c
     hi = h;
 }
 
+// a.early_pick (the only shard): when no chain is needed -- the usual case once a lone candidate's exact sum may come
+// later (af_defer.hip.h) or is not wanted -- this workgroup also makes the iteration's pick.
 __global__ __launch_bounds__(1024) void k_cand(PickArgs a)
 {
     __shared__ double wmax[16];
     __shared__ unsigned n_c;
-    __shared__ int inexact, any_inexact, zero_est;
+    __shared__ int inexact, any_inexact, zero_est, chain_needed;
     IterState *st = a.st;
     if (st->done) return;
     const unsigned n_active = st->n_active;
@@ -94,9 +96,14 @@ __global__ __launch_bounds__(1024) void k_cand(PickArgs a)
         // one candidate only: the argmax is settled (its estimate is also the largest); its exact float64 sum is
         // needed just for the reported score, which the caller may not want
         // (... unless its estimate is 0 while it has addends: the stop rule compares the score with 0, select.py:51)
-        st->need_chain = inexact && (zero_est || !(a.af_skip_single && n_c == 1));
+        chain_needed = inexact && (zero_est || !(a.af_skip_single && n_c == 1));
+        st->need_chain = chain_needed;
+        st->chain_events += chain_needed ? 1 : 0;
         st->all_exact = !any_inexact;
     }
+    if (!a.early_pick) return;
+    __syncthreads();
+    if (!chain_needed) pick_body<0>(a);
 }
 
 
@@ -130,6 +137,7 @@ __device__ __forceinline__ double ordered_sum64(double acc, double v)
 struct ChainSeg {
     int chunk;
     u64 w0;
+    u64 off;  // the segment's first word inside a whole-column buffer (chunks back to back)
 };
 struct ChainFast {
     const ChainSeg *segs;
@@ -202,7 +210,9 @@ __global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict_
 // a partial sum that reaches 2^53 may round, but never back below 2^53, which is all the crossing test needs.
 // ------------------------------------------------------------------------------------------------
 #define UTM_PAR_E 4
+#ifndef UTM_PAR_HEAD
 #define UTM_PAR_HEAD 256
+#endif
 #define UTM_PAR_MAX_SEGS 4095
 __device__ __forceinline__ unsigned pm_then(unsigned first, unsigned second)  // maps on {0,1}: bit p = image of p
 {
@@ -256,17 +266,44 @@ struct ParScratch {       // LDS
     double crossed;       // the running sum right after the crossing addend
 };
 
-// vals: this candidate's compacted addends, segment g's at vals + g * seg_cap; offs (LDS): exclusive prefix of the
-// segments' counts, n_segs + 1 entries.  Every thread of the 1024 calls this; every thread returns the sum.
-__device__ __forceinline__ double chain_parallel(const double *__restrict__ vals, size_t seg_cap, const unsigned *offs, int n_segs,
-                                                 ParScratch &sc)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned total = offs[n_segs];
-    auto value_at = [&](unsigned g, int &seg) -> double {  // seg: a segment at or before g's, advanced to g's
+// Where a chain's addends come from.  at(g, hint): addend g (g < total), `hint` a cursor the source may advance
+// (callers walk g upwards); first(g): a cursor for addend g.
+struct SegmentedAddends {  // k_chain_fill's layout: segment i's addends at vals + i * seg_cap; offs (LDS): exclusive
+    const double *vals;    // prefix of the segments' counts, n_segs + 1 entries
+    size_t seg_cap;
+    const unsigned *offs;
+    int n_segs;
+    __device__ __forceinline__ unsigned total() const { return offs[n_segs]; }
+    __device__ __forceinline__ int first(unsigned g) const
+    {  // binary search: last segment whose offset is <= g
+        int lo = 0, hi = n_segs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (offs[mid] <= g) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    }
+    __device__ __forceinline__ double at(unsigned g, int &seg) const
+    {
         while (g >= offs[seg + 1]) ++seg;
         return vals[(size_t)seg * seg_cap + (g - offs[seg])];
-    };
+    }
+};
+struct FlatAddends {  // one contiguous array
+    const double *vals;
+    unsigned n;
+    __device__ __forceinline__ unsigned total() const { return n; }
+    __device__ __forceinline__ int first(unsigned) const { return 0; }
+    __device__ __forceinline__ double at(unsigned g, int &) const { return vals[g]; }
+};
+
+// Every thread of the 1024 calls this; every thread returns the sum.
+template <class ADDENDS>
+__device__ __forceinline__ double chain_parallel(const ADDENDS &src, ParScratch &sc)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned total = src.total();
     // The first UTM_PAR_HEAD addends one by one (wave 0, registers only): a sum leaves a binade every few addends at
     // its start, and every crossing would cost the scan a round of its own.
     const unsigned head = total < UTM_PAR_HEAD ? total : UTM_PAR_HEAD;
@@ -274,7 +311,7 @@ __device__ __forceinline__ double chain_parallel(const double *__restrict__ vals
         double first = 0.0;
         for (unsigned t = 0; t < head; t += 64) {
             int seg = 0;
-            first = ordered_sum64(first, t + lane < head ? value_at(t + lane, seg) : 0.0);
+            first = ordered_sum64(first, t + lane < head ? src.at(t + lane, seg) : 0.0);
         }
         if (lane == 0) sc.crossed = first;
     }
@@ -287,18 +324,9 @@ __device__ __forceinline__ double chain_parallel(const double *__restrict__ vals
         const unsigned g0 = base + (unsigned)tid * UTM_PAR_E;
         double a[UTM_PAR_E];
         {
-            int seg = 0;
-            if (g0 < total) {  // binary search: last segment whose offset is <= g0
-                int lo = 0, hi = n_segs - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (offs[mid] <= g0) lo = mid;
-                    else hi = mid - 1;
-                }
-                seg = lo;
-            }
+            int seg = g0 < total ? src.first(g0) : 0;
 #pragma unroll
-            for (int j = 0; j < UTM_PAR_E; ++j) a[j] = g0 + j < total ? value_at(g0 + j, seg) : 0.0;
+            for (int j = 0; j < UTM_PAR_E; ++j) a[j] = g0 + j < total ? src.at(g0 + j, seg) : 0.0;
         }
         const unsigned end = total - base > 1024u * UTM_PAR_E ? base + 1024u * UTM_PAR_E : total;
         unsigned done = base > head ? base : head;  // addends [base, done) are in acc already
@@ -408,6 +436,7 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
                                                 const PickArgs pa, unsigned *__restrict__ arrivals)
 {
     if (st->done) return;  // (uniform over the launch: nobody arrives, nobody picks)
+    if (PICK && pa.early_pick && !st->need_chain) return;  // (... and so is this: k_cand has made the pick already)
     chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore);
     if (PICK) {
         __shared__ int last;
@@ -476,7 +505,8 @@ __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks,
                 off += c4[j];
             }
             __syncthreads();
-            const double sum = chain_parallel(f.vals + (size_t)blockIdx.x * f.n_segs * f.seg_cap, f.seg_cap, offs, f.n_segs, sc);
+            const SegmentedAddends src{f.vals + (size_t)blockIdx.x * f.n_segs * f.seg_cap, f.seg_cap, offs, f.n_segs};
+            const double sum = chain_parallel(src, sc);
             if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[blockIdx.x]), __builtin_bit_cast(u64, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }

@@ -44,6 +44,7 @@ struct IterState {
     // the winners' own counts, is the number of AF values the delta passes in between gathered (byte accounting)
     u64 cnt_sum_base;   // right after the first full pass and its pick
     u64 cnt_sum;        // at the end of the last batch
+    u64 chain_events;   // iterations so far whose pick needed chains on the spot (k_cand)
 };
 
 // The first 32 bytes of IterState: what a scoring workgroup needs at its start, fetched with one scalar load.
@@ -115,6 +116,8 @@ struct PickArgs {
     int af_is_f64;   // the estimate sums float32-rounded values of float64 AFs
     int af_trunc;    // the fixed-point unit is coarser than the smallest AF's last bit: every addend may lose < 1 unit
     int af_skip_single;  // a single candidate is the winner whatever its exact sum is: skip its chain, report the estimate
+    int early_pick;      // the only shard: k_cand also makes the pick when no chain is needed (the chain launches behind it
+                         // then return at once; when one is needed, their last workgroup picks)
     Rec *recs;       // every shard's record of the current iteration, recs[rank]
     int remote_winner_test;  // test hook: treat a local winner's column as remote too (it is then read from the
                              // winner-column buffer the exchange filled), so that one rank can exercise that path

@@ -3,12 +3,6 @@
 #pragma once
 
 // ---------------------------------------------------------------------------------------- launches
-static int tune_env(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 // Start / stop events of ONE scoring dispatch (UTM_FLAG_PROFILE_EVENTS): handed to hipExtLaunchKernelGGL, which
 // stamps them from the dispatch itself -- the kernel's own duration, as a kernel trace reports it (events recorded
 // around the launch add ~5 us of bracket to every measurement).  Null events = a plain launch.
@@ -137,7 +131,9 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
 #define UTM_LAUNCH_AFS(S, Q)                                                                                              \
     hipExtLaunchKernelGGL((k_score_afs<S, Q>), dim3(blocks), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,       \
                           ch.covered, ch.wp, afb, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,   \
-                          (unsigned)group, n_groups, (delta && !fold) ? ch.mask : nullptr, (delta && fold) ? ch.covered_alt : nullptr)
+                          (unsigned)group, n_groups, (delta && !fold) ? ch.mask : nullptr, (delta && fold) ? ch.covered_alt : nullptr, \
+                          (delta && fold && defer_active(c) && c->enq_iter > 0)                                                       \
+                              ? c->d_newly_log + (u64)((c->enq_iter - 1) % UTM_DEFER_SLOTS) * c->col_words + ch.off : nullptr)
         if (steps == 32) UTM_LAUNCH_AFS(32, 8);  // second argument: queue depth per lane
         else if (steps == 16) UTM_LAUNCH_AFS(16, 16);
         else if (steps == 8) UTM_LAUNCH_AFS(8, 16);
@@ -277,10 +273,8 @@ static i64 iteration_bytes(const utm_ctx *c, u64 a, int kind = -1)
 
 // Verified-parallel AF: candidates -> their chains (-> everyone, if too many tie) [-> the pick, in the chain launch's
 // last workgroup, when `pick_inside`].  Returns whether the pick was enqueued with it.
-static bool enqueue_candidates(utm_ctx *c, const PickArgs &a, bool pick_inside)
+static void enqueue_chains(utm_ctx *c, const PickArgs &a, bool pick_inside)
 {
-    if (!a.cand) return false;
-    hipLaunchKernelGGL(k_cand, dim3(1), dim3(c->active_ub > 512 ? 1024 : 256), 0, c->stream, a);
     const unsigned seq_blocks = (std::max(1u, c->active_ub) + 1023) / 1024;  // (only busy when the candidate list overflowed)
     const ChainFast &cf = c->chain_fast;
     const dim3 grid(UTM_MAX_CAND + seq_blocks);
@@ -300,6 +294,14 @@ static bool enqueue_candidates(utm_ctx *c, const PickArgs &a, bool pick_inside)
         else UTM_LAUNCH_CHAIN(double, false);
     }
 #undef UTM_LAUNCH_CHAIN
+}
+
+static bool enqueue_candidates(utm_ctx *c, PickArgs a, bool pick_inside)
+{
+    if (!a.cand) return false;
+    a.early_pick = pick_inside ? 1 : 0;
+    hipLaunchKernelGGL(k_cand, dim3(1), dim3(c->active_ub > 512 ? 1024 : 256), 0, c->stream, a);
+    enqueue_chains(c, a, pick_inside);
     return pick_inside;
 }
 
@@ -373,6 +375,46 @@ static int collect_event_times(utm_ctx *c)
     return UTM_OK;
 }
 
+// Deferred exact scores: finish result rows [lo, hi) -- their newly-covered masks are in the log.
+static int defer_finish_rows(utm_ctx *c, i64 lo, i64 hi)
+{
+    if (hi <= lo) return UTM_OK;
+    if (hi - lo > UTM_DEFER_SLOTS) return fail(UTM_ESTATE, "deferred scores: %lld rows in one go (internal error)", (long long)(hi - lo));
+    DeferArgs d;
+    d.chunks = c->d_seq;
+    d.segs = c->d_segs;
+    d.n_segs = c->chain_fast.n_segs;
+    d.log = c->d_newly_log;
+    d.col_words = c->col_words;
+    d.counts = c->d_defer_counts;
+    d.offs = c->d_defer_offs;
+    d.vals = c->d_defer_vals;
+    d.row0 = lo;
+    d.n_rows = (int)(hi - lo);
+    const dim3 grid((unsigned)d.n_segs, (unsigned)d.n_rows);
+    hipLaunchKernelGGL(k_defer_count, grid, dim3(256), 0, c->stream, d);
+    hipLaunchKernelGGL(k_defer_scan, dim3(1), dim3(1024), 0, c->stream, d);
+    if (c->af_mode == UTM_AF_F32) hipLaunchKernelGGL(k_defer_fill<float>, grid, dim3(1024), 0, c->stream, d);
+    else hipLaunchKernelGGL(k_defer_fill<double>, grid, dim3(1024), 0, c->stream, d);
+    hipLaunchKernelGGL(k_defer_chain, dim3((unsigned)d.n_rows), dim3(1024), 0, c->stream, d, (const i64 *)c->d_res_idx, c->d_res_score,
+                       c->have_weights ? (const double *)c->d_weights : nullptr);
+    HIP_TRY(hipGetLastError());
+    c->deferred_rows += hi - lo;
+    c->defer_lo = hi;
+    return UTM_OK;
+}
+
+// ... and the last row of a run, whose mask no later pass has made: pending winner & ~covered, then as above.
+// Call with the device idle at a batch boundary (the host's covered roles are settled there).
+static int defer_flush_last(utm_ctx *c)
+{
+    if (c->defer_lo >= c->iter) return UTM_OK;
+    for (auto &ch : c->chunks)
+        hipLaunchKernelGGL(k_newly_log, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream, ch.covered, ch.cols,
+                           ch.wp, pending_of(c, ch, false), (const IterState *)c->d_st, c->d_newly_log + ch.off, c->col_words);
+    return defer_finish_rows(c, c->defer_lo, c->iter);
+}
+
 extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new_out, double *score_out,
                        int64_t *n_done)
 {
@@ -391,6 +433,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     // (RCCL exchange: one iteration per sync -- the column broadcast's root is only known on the host after it)
     const int batch = rccl_needs_root(c) ? 1 : batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
     i64 enq = 0;
+    bool tail_deferred = false;  // the last batch left its last row's exact score to the end of the run
     while (enq < k_max && !c->finished) {
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
         // ... and so is the switch to decremental iterations
@@ -408,11 +451,16 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // are delta passes (enqueue_score); the byte accounting below tells them apart
         const bool af_par = c->af_mode != UTM_AF_NONE && c->af_fixed && !decr;
         const bool first_is_full = af_par && !c->keep_valid;
+        // deferred exact scores: this batch's delta passes log the masks of rows [iter - 1, ...) (a full pass logs
+        // nothing: the row in front of it was finished when the run that made it ended)
+        const bool defer = af_par && defer_active(c);
+        if (defer) c->defer_lo = std::max(c->defer_lo, first_is_full ? c->iter : c->iter - 1);
         const i64 swaps0 = c->cov_swaps_enqueued;
         // where the pick runs: inside the scoring launch on the only shard (1) and on a shard of the mailbox exchange (2)
         const int fuse_mode = (c->n_ranks > 1 && c->mbox_ok) ? 2 : (c->n_ranks == 1 && c->n_local == c->n_total && !c->comm) ? 1 : 0;
         for (i64 j = 0; j < n; ++j) {
             bool picked = false;
+            c->enq_iter = c->iter + j;  // (exact unless the loop ends first -- and then these launches do nothing)
             if (decr) TRY(enqueue_score_decr(c));
             else TRY(enqueue_score(c, false, fuse_mode, &picked));
             if (!picked) TRY(enqueue_pick_and_exchange(c, decr));
@@ -420,9 +468,9 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
             if (c->n_ranks == 1 && c->active_ub > 0) c->active_ub -= 1;  // exact while the loop is alive
         }
         if (af_par) hipLaunchKernelGGL(k_count_sum, dim3(1), dim3(1024), 0, c->stream, c->d_st, c->d_act, c->d_cnt, 0);
-        enq += n;
         const i64 before = c->iter;
         TRY(sync_state(c));
+        enq += n;
         if (rccl_needs_root(c) && c->iter > before && !c->finished) {
             // second half of the RCCL exchange: the winner's column from its owner into every shard's winner-column
             // buffer, where the next scoring pass ORs it into covered (select.py:100 on every replica)
@@ -479,9 +527,16 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // a full pass mirrored the counts (integer mode with the decremental option) / the AF accumulators are persistent
         c->keep_valid = c->decr_enabled || (c->af_mode != UTM_AF_NONE && c->af_fixed);
         if (rows > 0) HIP_TRY(copy_sync(c, &c->last_new, c->d_res_new + c->iter - 1, 8, hipMemcpyDeviceToHost));
+        if (defer) {
+            // pass j scored iteration before + j and logged row before + j - 1
+            TRY(defer_finish_rows(c, c->defer_lo, before + passes - 1));
+            if (!defer_active(c)) TRY(defer_flush_last(c));  // (the estimates just became exact: no later pass will log)
+        }
+        tail_deferred = defer;
         c->scored += passes;
         if (c->flags & UTM_FLAG_PROFILE_EVENTS) TRY(collect_event_times(c));
     }
+    if (tail_deferred) TRY(defer_flush_last(c));
     HIP_TRY(hipEventRecord(c->ev_loop1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev_loop1));
     float ms = 0;
@@ -579,6 +634,8 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
                     : (c->n_ranks > 1 && c->mbox_ok)     ? UTM_EXCHANGE_MAILBOX
                     : c->comm                            ? (c->column_by_allreduce ? UTM_EXCHANGE_RCCL_SUM : UTM_EXCHANGE_RCCL)
                                                          : UTM_EXCHANGE_CALLER;
+    out->af_chained_iterations = c->prepared ? (i64)c->h_st->chain_events : 0;
+    out->af_deferred_rows = c->deferred_rows;
     out->rccl_ranks = 0;
     if (c->comm) {
         int n = 0;

@@ -194,7 +194,7 @@ static int build_af_tables(utm_ctx *c)
     if (c->af_fixed) {
         std::vector<ChainSeg> segs;
         for (size_t k = 0; k < c->chunks.size(); ++k)
-            for (u64 w0 = 0; w0 < c->chunks[k].w; w0 += UTM_SEG_WORDS) segs.push_back(ChainSeg{(int)k, w0});
+            for (u64 w0 = 0; w0 < c->chunks[k].w; w0 += UTM_SEG_WORDS) segs.push_back(ChainSeg{(int)k, w0, c->chunks[k].off + w0});
         const size_t n = segs.size();
         // regions for the candidates' compacted addends: room for EVERY bit of a segment where the memory allows
         // (all candidates, then two), so that the parallel chain always applies; else 1024 values per segment and
@@ -216,6 +216,22 @@ static int build_af_tables(utm_ctx *c)
             c->chain_fast.n_segs = (int)n;
             c->chain_fast.seg_cap = cap;
             c->chain_fast.n_cand = n_cand;
+        }
+        // deferred exact scores (af_defer.hip.h): the mask log, one addend slot per variant, (row, segment) tables --
+        // only where the loop can use them (the only shard) and the memory is to spare; without them every winner is
+        // chained on the spot, as before
+        (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
+        c->d_newly_log = nullptr; c->d_defer_counts = nullptr; c->d_defer_offs = nullptr; c->d_defer_vals = nullptr;
+        static const int defer_env = tune_env("UTM_AF_DEFER", 1);
+        u64 slots = 0;  // addend slots: every word that holds variants
+        for (auto &ch : c->chunks) slots += ch.w * 64;
+        const size_t need = (size_t)UTM_DEFER_SLOTS * c->col_words * 8 + slots * 8 + (size_t)UTM_DEFER_SLOTS * n * 12 + 8;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (defer_env && cap && c->d_segs && c->n_local == c->n_total && slots < 0xFFFF0000ull && need <= free_b / 4) {
+            HIP_TRY(hipMalloc(&c->d_newly_log, (size_t)UTM_DEFER_SLOTS * c->col_words * 8));
+            HIP_TRY(hipMalloc(&c->d_defer_vals, slots * 8));
+            HIP_TRY(hipMalloc(&c->d_defer_counts, (size_t)UTM_DEFER_SLOTS * n * 4));
+            HIP_TRY(hipMalloc(&c->d_defer_offs, ((size_t)UTM_DEFER_SLOTS * n + 1) * 8));
         }
     }
     c->dirty_tables = false;

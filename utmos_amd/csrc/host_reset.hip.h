@@ -183,6 +183,8 @@ extern "C" int utm_reset(utm_ctx *c)
     c->iter = 0;
     c->captured_seen = 0;
     c->af_all_exact = false;
+    c->defer_lo = 0;
+    c->deferred_rows = 0;
     c->scored = 0;
     c->active_ub = (unsigned)act.size();
     c->finished = false;
@@ -238,7 +240,10 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     a.af_is_f64 = c->af_mode == UTM_AF_F64;
     a.af_trunc = c->af_trunc ? 1 : 0;
     // (a shard's record is compared with other shards' records: there the score has to be exact)
-    a.af_skip_single = (!c->af_exact_scores && c->n_local == c->n_total) ? 1 : 0;
+    // ... and so it is for the caller unless told otherwise -- but on the only shard a lone candidate's exact sum can
+    // come later, from the deferred launches
+    a.af_skip_single = ((!c->af_exact_scores || defer_active(c)) && c->n_local == c->n_total) ? 1 : 0;
+    a.early_pick = 0;  // (enqueue_candidates decides)
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
     a.remote_winner_test = c->remote_winner_test ? 1 : 0;
     a.res_idx = c->d_res_idx;

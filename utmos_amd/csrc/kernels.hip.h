@@ -8,4 +8,5 @@
 #include "covered.hip.h"
 #include "decremental.hip.h"
 #include "af_verify.hip.h"
+#include "af_defer.hip.h"
 #include "ingest.hip.h"

@@ -298,7 +298,9 @@ __device__ __forceinline__ void pick_body(const PickArgs &a)
             if (better(cand, best)) best = cand;
         }
     }
-    for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
+    // (candidates' chains with persistent accumulators: nothing to read, clear or mirror per sample)
+    const bool scan_samples = !(src == 3 && !a.zero_after && !a.cnt_mirror && !a.afsum_mirror);
+    for (unsigned i = threadIdx.x; scan_samples && i < n_active; i += blockDim.x) {
         const unsigned s = a.act[i];
         const unsigned ci = a.cnt_by_pos ? i : s;
         const u64 c = a.cnt[ci];

@@ -22,6 +22,7 @@ __device__ __forceinline__ u64 af_fixed(unsigned f)
 // a * 2^q = af_fixed(table entry).
 // ------------------------------------------------------------------------------------------------
 #define UTM_AF_TILE_WORDS 128
+#define UTM_DEFER_SLOTS 64  // iterations whose newly-covered masks the log holds (af_defer.hip.h)
 __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const unsigned *__restrict__ af,
                                                    const Pending pend,
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
                                                    unsigned n_groups, const u64 *__restrict__ delta_mask,
-                                                   u64 *__restrict__ covered_out)
+                                                   u64 *__restrict__ covered_out, u64 *__restrict__ newly_log)
 {
     __shared__ v4u live[STEPS * 64];
     __shared__ unsigned queue[4][CAP][64];
@@ -142,10 +143,14 @@ __global__ __launch_bounds__(256) void k_score_afs(const u64 *__restrict__ cols,
         const u64 *wcol = pending_column(st, cols, wp, pend);
         const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
         const v4u zero4 = {0, 0, 0, 0};
+        // newly_log: the mask is also what the last winner's exact float64 score runs over (af_defer.hip.h): group 0
+        // leaves it in that row's slot of the log (the host passes this chunk's part of the slot)
+        v4u *lg = (newly_log && wc && grp == 0) ? reinterpret_cast<v4u *>(newly_log + w0) : nullptr;
         for (int i = threadIdx.x; i < nsteps * 64; i += 256) {
             const v4u c = cv[i];
             const v4u w = wc ? wc[i] : zero4;
             if (grp == 0) co[i] = c | w;
+            if (lg) lg[i] = w & ~c;
             live[i] = w & ~c;
         }
     } else if (delta_mask) {

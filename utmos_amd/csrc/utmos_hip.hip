@@ -170,6 +170,14 @@ struct utm_ctx {
     unsigned *d_arrivals = nullptr;  // workgroups of a k_chain launch that have finished (its last one runs the pick)
     ChainFast chain_fast{nullptr, 0, nullptr, nullptr, 0, 0};  // device buffers of the chains' fast path
     ChainSeg *d_segs = nullptr;
+    // deferred exact AF scores (af_defer.hip.h): the log of newly-covered masks and the finishing launches' buffers
+    u64 *d_newly_log = nullptr;       // [UTM_DEFER_SLOTS][col_words], or null (no room / not the only shard's AF loop)
+    unsigned *d_defer_counts = nullptr;
+    u64 *d_defer_offs = nullptr;
+    double *d_defer_vals = nullptr;
+    i64 defer_lo = 0;                 // result rows below this one carry their final score
+    i64 enq_iter = 0;                 // utm_run: the iteration whose launches are being enqueued
+    i64 deferred_rows = 0;            // rows whose score came from the deferred launches (statistics)
     u64 *d_cnt_keep = nullptr;   // persistent per-sample counts (mirror of the last full scoring, then decremented)
     i64 *d_afsum_keep = nullptr;
     unsigned *d_listn = nullptr; // per chunk
@@ -247,6 +255,14 @@ static bool rccl_needs_root(const utm_ctx *c) { return rccl_exchange(c) && !c->c
 // Remote winners are read in place through the hipIpc mappings (not from a local copy / the broadcast buffer).
 static bool remote_reads(const utm_ctx *c) { return c->p2p && !c->replicated && !rccl_exchange(c); }
 
+// The AF loop leaves unambiguous winners' exact float64 scores to the deferred launches (af_defer.hip.h): the only
+// shard's verified-parallel loop, exact scores wanted, buffers in place, estimates not (yet) all exact.
+static bool defer_active(const utm_ctx *c)
+{
+    return c->d_newly_log && c->af_exact_scores && c->af_mode != UTM_AF_NONE && c->af_fixed && !c->af_all_exact && !c->decr_enabled &&
+           c->n_ranks == 1 && c->n_local == c->n_total && !c->comm && !c->p2p;
+}
+
 static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel)
 {
     Pending p;
@@ -264,7 +280,7 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
 static const char *const g_env_knobs[] = {
     "UTM_TARGET_WGS", "UTM_MIN_WGS", "UTM_MIN_WGS_BIG", "UTM_TILE_STEPS", "UTM_NT_LOADS", "UTM_NT_MIN_MB", "UTM_FUSE_PICK",
     "UTM_PICK_THREADS", "UTM_BATCH", "UTM_AF_STEPS", "UTM_AF_SWITCH", "UTM_AF_TARGET_WGS", "UTM_DECR_FIRST_BATCH",
-    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER", "UTM_CHAIN_PICK"};
+    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER", "UTM_CHAIN_PICK", "UTM_AF_DEFER"};
 static void report_env_once()
 {
     static bool said = false;
@@ -354,6 +370,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_arrivals);
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
+    (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
@@ -396,6 +413,12 @@ static int chunk_of(utm_ctx *c, int32_t chunk, Chunk **out)
     if (chunk < 0 || (size_t)chunk >= c->chunks.size()) return fail(UTM_EINVAL, "chunk %d not in [0,%zu)", chunk, c->chunks.size());
     *out = &c->chunks[chunk];
     return UTM_OK;
+}
+
+static int tune_env(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
 }
 
 #include "host_matrix.hip.h"
