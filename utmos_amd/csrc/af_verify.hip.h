@@ -42,68 +42,156 @@ __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c
     hi = h;
 }
 
-// a.early_pick (the only shard): when no chain is needed -- the usual case once a lone candidate's exact sum may come
-// later (af_defer.hip.h) or is not wanted -- this workgroup also makes the iteration's pick.
-__global__ __launch_bounds__(1024) void k_cand(PickArgs a)
+// Candidates of the iteration (see above) by ONE workgroup of 256 or 1024 threads; returns (to every thread) whether
+// chains are needed.  A thread keeps up to UTM_CAND_R samples' intervals in registers between the two passes (best
+// lower bound, then the list), so 2,504 samples cost one round of loads; more samples than that are read twice.
+// early_pick (the only shard): when no chain is needed -- the usual case once a lone candidate's exact sum may come
+// later (af_defer.hip.h) or is not wanted -- this workgroup also makes the iteration's pick, from the candidate
+// list alone: a sample outside it has its whole interval below the best lower bound, so it is not the argmax.
+#define UTM_CAND_R 4
+struct CandScratch {  // LDS
+    double wmax[16];
+    Cand wbest[16];
+    unsigned n_c;
+    int inexact, any_inexact, zero_est, chain_needed;
+};
+__device__ __forceinline__ bool cand_body(const PickArgs &a, CandScratch &sc, bool early_pick)
 {
-    __shared__ double wmax[16];
-    __shared__ unsigned n_c;
-    __shared__ int inexact, any_inexact, zero_est, chain_needed;
     IterState *st = a.st;
-    if (st->done) return;
     const unsigned n_active = st->n_active;
-    if (threadIdx.x == 0) { n_c = 0; inexact = 0; any_inexact = 0; zero_est = 0; }
+    Preloaded pre{0, 0, 0, 0};
+    if (early_pick && threadIdx.x == 0) {
+        pre.iter = st->iter;
+        pre.tot = st->tot;
+        pre.n_active_total = st->n_active_total;
+        pre.last_act = n_active ? a.act[n_active - 1] : 0;
+    }
+    if (threadIdx.x == 0) { sc.n_c = 0; sc.inexact = 0; sc.any_inexact = 0; sc.zero_est = 0; }
+    const bool in_regs = n_active <= UTM_CAND_R * blockDim.x;
+    unsigned rs[UTM_CAND_R];
+    u64 rc[UTM_CAND_R];
+    double rlo[UTM_CAND_R], rhi[UTM_CAND_R], rest[UTM_CAND_R];
+    bool rex[UTM_CAND_R];
     double best_lo = -__builtin_inf();
-    for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
-        const unsigned s = a.act[i];
-        double lo, hi, est;
-        bool exact;
-        af_interval(a, s, a.cnt[s], lo, hi, est, exact);
-        best_lo = lo > best_lo ? lo : best_lo;
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < UTM_CAND_R; ++r) {
+            const unsigned i = threadIdx.x + r * blockDim.x;
+            rs[r] = i < n_active ? a.act[i] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < UTM_CAND_R; ++r) {
+            const unsigned i = threadIdx.x + r * blockDim.x;
+            rc[r] = i < n_active ? a.cnt[rs[r]] : 0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < UTM_CAND_R; ++r) {
+            const unsigned i = threadIdx.x + r * blockDim.x;
+            rlo[r] = rhi[r] = -__builtin_inf();
+            rest[r] = 0.0;
+            rex[r] = true;
+            if (i < n_active) af_interval(a, rs[r], rc[r], rlo[r], rhi[r], rest[r], rex[r]);
+            best_lo = rlo[r] > best_lo ? rlo[r] : best_lo;
+        }
+    } else {
+        for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
+            const unsigned s = a.act[i];
+            double lo, hi, est;
+            bool exact;
+            af_interval(a, s, a.cnt[s], lo, hi, est, exact);
+            best_lo = lo > best_lo ? lo : best_lo;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const double other = __shfl_xor(best_lo, o, 64);
         best_lo = other > best_lo ? other : best_lo;
     }
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best_lo;
+    if ((threadIdx.x & 63) == 0) sc.wmax[threadIdx.x >> 6] = best_lo;
     __syncthreads();
-    best_lo = wmax[0];
-    for (unsigned w = 1; w < (blockDim.x >> 6); ++w) best_lo = fmax(best_lo, wmax[w]);
-    for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
-        const unsigned s = a.act[i];
-        const u64 c = a.cnt[s];
-        double lo, hi, est;
-        bool exact;
-        af_interval(a, s, c, lo, hi, est, exact);
-        if (!exact) any_inexact = 1;
+    best_lo = sc.wmax[0];
+    for (unsigned w = 1; w < (blockDim.x >> 6); ++w) best_lo = fmax(best_lo, sc.wmax[w]);
+    auto consider = [&](unsigned i, unsigned s, u64 c, double hi, double est, bool exact) {
+        if (!exact) sc.any_inexact = 1;
         if (hi >= best_lo) {
-            const unsigned slot = atomicAdd(&n_c, 1u);
+            const unsigned slot = atomicAdd(&sc.n_c, 1u);
             if (slot < UTM_MAX_CAND) {
                 a.cand->pos[slot] = i;
                 a.cand->samp[slot] = s;
                 a.cand->cnt[slot] = (i64)c;
                 a.cand->val[slot] = est;
             }
-            if (!exact) inexact = 1;
-            if (!exact && est == 0.0) zero_est = 1;  // coarse unit: every addend floored away, yet the true score is > 0
+            if (!exact) sc.inexact = 1;
+            if (!exact && est == 0.0) sc.zero_est = 1;  // coarse unit: every addend floored away, yet the true score is > 0
+        }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int r = 0; r < UTM_CAND_R; ++r) {
+            const unsigned i = threadIdx.x + r * blockDim.x;
+            if (i < n_active) consider(i, rs[r], rc[r], rhi[r], rest[r], rex[r]);
+        }
+    } else {
+        for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
+            const unsigned s = a.act[i];
+            const u64 c = a.cnt[s];
+            double lo, hi, est;
+            bool exact;
+            af_interval(a, s, c, lo, hi, est, exact);
+            consider(i, s, c, hi, est, exact);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const unsigned n_c = sc.n_c;
         st->n_cand = n_c < UTM_MAX_CAND ? (int)n_c : UTM_MAX_CAND;
         st->cand_overflow = n_c > UTM_MAX_CAND;
         // one candidate only: the argmax is settled (its estimate is also the largest); its exact float64 sum is
         // needed just for the reported score, which the caller may not want
         // (... unless its estimate is 0 while it has addends: the stop rule compares the score with 0, select.py:51)
-        chain_needed = inexact && (zero_est || !(a.af_skip_single && n_c == 1));
-        st->need_chain = chain_needed;
-        st->chain_events += chain_needed ? 1 : 0;
-        st->all_exact = !any_inexact;
+        sc.chain_needed = sc.inexact && (sc.zero_est || !(a.af_skip_single && n_c == 1));
+        st->need_chain = sc.chain_needed;
+        st->chain_events += sc.chain_needed ? 1 : 0;
+        st->all_exact = !sc.any_inexact;
     }
-    if (!a.early_pick) return;
     __syncthreads();
-    if (!chain_needed) pick_body<0>(a);
+    const bool chain_needed = sc.chain_needed != 0;
+    if (!early_pick || chain_needed) return chain_needed;
+    const unsigned n_c = sc.n_c;
+    if (n_c == 0 || n_c > UTM_MAX_CAND || a.list_n) {  // (no list to pick from / decremental bookkeeping: the general pick)
+        pick_body<0>(a);
+        return false;
+    }
+    if (threadIdx.x < 64) {  // the pick among the candidates: mask / weight / argmax as in pick_body, one lane each
+        Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+        if (threadIdx.x < n_c) {
+            const unsigned s = a.cand->samp[threadIdx.x];
+            double v = a.cand->val[threadIdx.x];
+            if (a.weights) v *= a.weights[a.first + s];
+            best = Cand{v, (i64)a.first + s, a.cand->cnt[threadIdx.x], a.cand->pos[threadIdx.x]};
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const Cand other = shfl_cand(best, o);
+            if (better(other, best)) best = other;
+        }
+        if (threadIdx.x == 0) {
+            Rec *rc0 = rec_of(a, a.rank);
+            rc0->score = best.val;
+            rc0->idx = best.gidx;
+            rc0->new_count = best.cnt;
+            st->best_pos = best.pos;
+            decide_single(a, best, n_active, pre);
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(1024) void k_cand(PickArgs a)
+{
+    __shared__ CandScratch sc;
+    if (a.st->done) return;
+    cand_body(a, sc, a.early_pick != 0);
 }
 
 
