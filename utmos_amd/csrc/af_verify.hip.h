@@ -55,11 +55,10 @@ struct CandScratch {  // LDS
     unsigned n_c;
     int inexact, any_inexact, zero_est, chain_needed;
 };
-__device__ __forceinline__ bool cand_body(const PickArgs &a, CandScratch &sc, bool early_pick)
+__device__ __forceinline__ bool cand_list(const PickArgs &a, CandScratch &sc, bool early_pick, Preloaded &pre)
 {
     IterState *st = a.st;
     const unsigned n_active = st->n_active;
-    Preloaded pre{0, 0, 0, 0};
     if (early_pick && threadIdx.x == 0) {
         pre.iter = st->iter;
         pre.tot = st->tot;
@@ -155,12 +154,18 @@ __device__ __forceinline__ bool cand_body(const PickArgs &a, CandScratch &sc, bo
         st->all_exact = !sc.any_inexact;
     }
     __syncthreads();
-    const bool chain_needed = sc.chain_needed != 0;
-    if (!early_pick || chain_needed) return chain_needed;
+    return sc.chain_needed != 0;
+}
+
+// ... and the pick when cand_list found that no chain is needed (early_pick).
+__device__ __forceinline__ void cand_pick(const PickArgs &a, CandScratch &sc, const Preloaded &pre)
+{
+    IterState *st = a.st;
+    const unsigned n_active = st->n_active;
     const unsigned n_c = sc.n_c;
     if (n_c == 0 || n_c > UTM_MAX_CAND || a.list_n) {  // (no list to pick from / decremental bookkeeping: the general pick)
         pick_body<0>(a);
-        return false;
+        return;
     }
     if (threadIdx.x < 64) {  // the pick among the candidates: mask / weight / argmax as in pick_body, one lane each
         Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
@@ -184,14 +189,15 @@ __device__ __forceinline__ bool cand_body(const PickArgs &a, CandScratch &sc, bo
             decide_single(a, best, n_active, pre);
         }
     }
-    return false;
 }
 
 __global__ __launch_bounds__(1024) void k_cand(PickArgs a)
 {
     __shared__ CandScratch sc;
     if (a.st->done) return;
-    cand_body(a, sc, a.early_pick != 0);
+    Preloaded pre{0, 0, 0, 0};
+    const bool chain_needed = cand_list(a, sc, a.early_pick != 0, pre);
+    if (a.early_pick && !chain_needed) cand_pick(a, sc, pre);
 }
 
 
@@ -236,15 +242,16 @@ struct ChainFast {
     int n_cand;        // candidates with buffers (<= UTM_FAST_CAND)
 };
 
+// (seg, ci): the segment and the candidate this workgroup of 1024 compacts; wtot: 16 words of LDS
 template <typename AF_T>
-__global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict__ chunks, const IterState *__restrict__ st,
-                                                     const CandBuf *__restrict__ cand, ChainFast f)
+__device__ __forceinline__ void chain_fill_block(const SeqChunk *__restrict__ chunks, const CandBuf *__restrict__ cand,
+                                                 const ChainFast &f, unsigned seg, unsigned ci, unsigned *wtot)
 {
-    __shared__ unsigned wtot[16];
-    if (st->done || !st->need_chain || st->cand_overflow || st->n_cand > f.n_cand || (int)blockIdx.y >= st->n_cand) return;
-    const ChainSeg sg = f.segs[blockIdx.x];
+    // (k_verify: the list was written, and the addends are read, by workgroups that may sit on another XCD -- the
+    // sample index comes through an agent-scope load, counts and values leave through agent-scope stores)
+    const ChainSeg sg = f.segs[seg];
     const SeqChunk ch = chunks[sg.chunk];
-    const unsigned s = cand->samp[blockIdx.y];
+    const unsigned s = __hip_atomic_load(&cand->samp[ci], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 *col = ch.cols + (u64)s * ch.wp;
     const AF_T *af = static_cast<const AF_T *>(ch.af);
@@ -266,8 +273,8 @@ __global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict_
         woff += k < wave ? t : 0;
         total += t;
     }
-    const size_t slot = (size_t)blockIdx.y * f.n_segs + blockIdx.x;
-    if (tid == 0) f.counts[slot] = total <= f.seg_cap ? total : 0xFFFFFFFFu;
+    const size_t slot = (size_t)ci * f.n_segs + seg;
+    if (tid == 0) __hip_atomic_store(&f.counts[slot], total <= f.seg_cap ? total : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (total == 0 || total > f.seg_cap) return;
     double *out = f.vals + slot * f.seg_cap + (woff + incl - n);
 #pragma unroll
@@ -276,9 +283,19 @@ __global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict_
         while (y) {
             const int b = __builtin_ctzll(y);
             y &= y - 1;
-            *out++ = (double)af[(w + k) * 64 + b];
+            __hip_atomic_store(reinterpret_cast<u64 *>(out++), __builtin_bit_cast(u64, (double)af[(w + k) * 64 + b]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+template <typename AF_T>
+__global__ __launch_bounds__(1024) void k_chain_fill(const SeqChunk *__restrict__ chunks, const IterState *__restrict__ st,
+                                                     const CandBuf *__restrict__ cand, ChainFast f)
+{
+    __shared__ unsigned wtot[16];
+    if (st->done || !st->need_chain || st->cand_overflow || st->n_cand > f.n_cand || (int)blockIdx.y >= st->n_cand) return;
+    chain_fill_block<AF_T>(chunks, cand, f, blockIdx.x, blockIdx.y, wtot);
 }
 
 
@@ -512,7 +529,8 @@ __device__ __forceinline__ double chain_parallel(const ADDENDS &src, ParScratch 
 template <typename AF_T>
 __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks, int n_chunks, const IterState *__restrict__ st,
                                             CandBuf *__restrict__ cand, const ChainFast &f, const unsigned *__restrict__ act,
-                                            u64 *__restrict__ cnt, double *__restrict__ fscore);
+                                            u64 *__restrict__ cnt, double *__restrict__ fscore, unsigned bx, bool need_chain,
+                                            bool overflow, int n_cand);
 
 // PICK: the iteration's pick (k_pick<0>'s body) runs in whichever workgroup of this launch finishes last -- one launch
 // less per iteration wherever candidates are verified (float64 AF: every iteration).  Arrival is one returning atomic
@@ -525,7 +543,7 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
 {
     if (st->done) return;  // (uniform over the launch: nobody arrives, nobody picks)
     if (PICK && pa.early_pick && !st->need_chain) return;  // (... and so is this: k_cand has made the pick already)
-    chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore);
+    chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore, blockIdx.x, st->need_chain != 0, st->cand_overflow != 0, st->n_cand);
     if (PICK) {
         __shared__ int last;
         __syncthreads();
@@ -549,25 +567,26 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
 template <typename AF_T>
 __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks, int n_chunks, const IterState *__restrict__ st,
                                             CandBuf *__restrict__ cand, const ChainFast &f, const unsigned *__restrict__ act,
-                                            u64 *__restrict__ cnt, double *__restrict__ fscore)
+                                            u64 *__restrict__ cnt, double *__restrict__ fscore, unsigned bx, bool need_chain,
+                                            bool overflow, int n_cand)
 {
     __shared__ double buf[UTM_CHAIN_CAP];
     __shared__ unsigned wtot[2][16];  // double buffered: one barrier per empty round
     __shared__ int dense;
-    if (!st->need_chain) return;
-    if (blockIdx.x >= UTM_MAX_CAND) {
-        const unsigned i = (blockIdx.x - UTM_MAX_CAND) * 1024 + threadIdx.x;
-        if (st->cand_overflow && i < st->n_active) seq_score_sample<AF_T>(chunks, n_chunks, act[i], cnt, fscore);
+    if (!need_chain) return;
+    if (bx >= UTM_MAX_CAND) {
+        const unsigned i = (bx - UTM_MAX_CAND) * 1024 + threadIdx.x;
+        if (overflow && i < st->n_active) seq_score_sample<AF_T>(chunks, n_chunks, act[i], cnt, fscore);
         return;
     }
-    if (st->cand_overflow || (int)blockIdx.x >= st->n_cand) return;
-    const unsigned s = cand->samp[blockIdx.x];
+    if (overflow || (int)bx >= n_cand) return;
+    const unsigned s = cand->samp[bx];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (f.counts && st->n_cand <= f.n_cand && f.n_segs <= UTM_PAR_MAX_SEGS) {
+    if (f.counts && n_cand <= f.n_cand && f.n_segs <= UTM_PAR_MAX_SEGS) {
         // k_chain_fill compacted this candidate's addends per segment: if every segment fitted its region, all 1024
         // threads run the parallel form of the chain over them
         __shared__ ParScratch sc;
-        const unsigned *cnts = f.counts + (size_t)blockIdx.x * f.n_segs;
+        const unsigned *cnts = f.counts + (size_t)bx * f.n_segs;
         unsigned *offs = reinterpret_cast<unsigned *>(buf);  // n_segs + 1 <= 4096 entries
         if (tid == 0) dense = 0;
         __syncthreads();
@@ -593,9 +612,9 @@ __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks,
                 off += c4[j];
             }
             __syncthreads();
-            const SegmentedAddends src{f.vals + (size_t)blockIdx.x * f.n_segs * f.seg_cap, f.seg_cap, offs, f.n_segs};
+            const SegmentedAddends src{f.vals + (size_t)bx * f.n_segs * f.seg_cap, f.seg_cap, offs, f.n_segs};
             const double sum = chain_parallel(src, sc);
-            if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[blockIdx.x]), __builtin_bit_cast(u64, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[bx]), __builtin_bit_cast(u64, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         __syncthreads();  // (dense: the one-workgroup chain below reuses buf)
@@ -657,5 +676,148 @@ __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks,
             }
         }
     }
-    if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[blockIdx.x]), __builtin_bit_cast(u64, acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[bx]), __builtin_bit_cast(u64, acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole verification of an iteration in ONE launch (the only shard): candidates -> their compacted addends ->
+// their chains -> the pick, as stages of one grid instead of three dependent launches (a dependent launch costs
+// ~4.4 us before its first instruction, needed or not).
+//   workgroup 0                      cand_list; publishes (launch number, chains needed?, how many candidates) in ONE
+//                                    64-bit word; when no chain is needed it goes on to make the pick itself
+//   workgroups [1, 1 + n_fill)       wait for that word; nothing to do -> return; else chain_fill_block for their
+//                                    (segment, candidate) and a count on the candidate's counter
+//   the last 64 + overflow ones      wait for the word, then (fast path) for their candidate's counter to show every
+//                                    segment; chain_block; the last one to arrive makes the pick (as k_chain<PICK>)
+// A stage only ever waits for workgroups with LOWER indices, and workgroups start in index order on each XCD, so the
+// ones waited for are running or done whatever else occupies the device; every wait is bounded all the same (a
+// time-out ends the loop with IterState::xerror = 2, which the host reports).
+// ------------------------------------------------------------------------------------------------
+struct VerifySync {  // device memory, zeroed by utm_reset; self-resetting from launch to launch
+    u64 stage1;      // [63:32] launch number, [17] chains needed, [16] candidate overflow, [15:0] candidates
+    unsigned filled[UTM_FAST_CAND];
+    unsigned arrivals;
+    unsigned pad_;
+#ifdef UTM_DEBUG_STAMPS
+    u64 stamps[16];
+#endif
+};
+#ifdef UTM_DEBUG_STAMPS
+#define UTM_STAMP(i) do { if (threadIdx.x == 0) vs->stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define UTM_STAMP(i) do { } while (0)
+#endif
+#define UTM_VERIFY_SPINS (1u << 22)
+
+// Memory order across workgroups (they may sit on different XCDs, each with its own L2): the stage words are read
+// and written with agent-scope atomics only, and nothing else is exchanged while no chain is needed -- the common
+// case costs no cache maintenance at all.  When chains are needed, a writer stage ends with: every wave's stores
+// acknowledged (s_waitcnt), barrier, ONE agent-scope release fence (L2 write-back) by thread 0, then the counter /
+// word; a reader stage starts with: the word seen, ONE agent-scope acquire fence (invalidate) by thread 0, barrier.
+__device__ __forceinline__ void stage_release()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+__device__ __forceinline__ void stage_acquire()
+{
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+}
+
+template <typename AF_T>
+__global__ __launch_bounds__(1024) void k_verify(const SeqChunk *__restrict__ chunks, int n_chunks, IterState *__restrict__ st,
+                                                 CandBuf *__restrict__ cand, ChainFast f, const unsigned *__restrict__ act,
+                                                 u64 *__restrict__ cnt, double *__restrict__ fscore, const PickArgs pa,
+                                                 VerifySync *__restrict__ vs, unsigned launch_no, unsigned n_fill)
+{
+    __shared__ CandScratch sc;  // (workgroup 0; the fill workgroups use its first words)
+    __shared__ u64 word;
+    __shared__ int last;
+    if (st->done) return;  // (set only by a pick: before this launch, or by this launch's own once nobody has work left)
+    if (blockIdx.x == 0) {
+        UTM_STAMP(0);
+        Preloaded pre{0, 0, 0, 0};
+        const bool chain_needed = cand_list(pa, sc, true, pre);
+        UTM_STAMP(1);
+        if (chain_needed) stage_release();
+        UTM_STAMP(2);  // (the candidate list, IterState's fields: only chains read them)
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&vs->stage1, ((u64)launch_no << 32) | (chain_needed ? 1u << 17 : 0u) | (st->cand_overflow ? 1u << 16 : 0u) |
+                                                (unsigned)st->n_cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!chain_needed) cand_pick(pa, sc, pre);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        u64 w = 0;
+        unsigned spin = 0;
+        for (; spin < UTM_VERIFY_SPINS; ++spin) {
+            w = __hip_atomic_load(&vs->stage1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32) == launch_no) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (spin == UTM_VERIFY_SPINS) {
+            st->xerror = 2;
+            st->done = 1;
+            w = 0;  // (nothing to do)
+        }
+        word = w;
+    }
+    __syncthreads();
+    const u64 w1 = word;
+    const bool chain_needed = (w1 >> 17) & 1, overflow = (w1 >> 16) & 1;
+    const int n_cand = (int)(w1 & 0xFFFF);
+    if (!chain_needed) return;
+    const bool fast = f.counts && !overflow && n_cand <= f.n_cand;
+    if (blockIdx.x <= n_fill) {
+        const unsigned j = blockIdx.x - 1, seg = j % (unsigned)f.n_segs, ci = j / (unsigned)f.n_segs;
+        if (!fast || (int)ci >= n_cand) return;
+        if (seg == 0 && ci == 0) UTM_STAMP(3);
+        chain_fill_block<AF_T>(chunks, cand, f, seg, ci, reinterpret_cast<unsigned *>(&sc));  // (coherent loads / stores inside)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (seg == 0 && ci == 0) UTM_STAMP(4);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&vs->filled[ci], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const unsigned bx = blockIdx.x - 1 - n_fill, n_chain_blocks = gridDim.x - 1 - n_fill;
+    const bool works = bx >= UTM_MAX_CAND ? overflow : (!overflow && (int)bx < n_cand);
+    if (works && bx == 0) UTM_STAMP(5);
+    if (works) {
+        if (fast) {  // this candidate's addends: every segment's workgroup has counted in
+            if (threadIdx.x == 0) {
+                unsigned spin = 0;
+                for (; spin < UTM_VERIFY_SPINS; ++spin) {
+                    if (__hip_atomic_load(&vs->filled[bx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)f.n_segs) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (spin == UTM_VERIFY_SPINS) st->xerror = 2;  // (the pick below still ends the iteration; the host reports the error)
+                __hip_atomic_store(&vs->filled[bx], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+        if (bx == 0) UTM_STAMP(6);
+        stage_acquire();  // the candidate list, IterState's fields, the compacted addends
+        if (bx == 0) UTM_STAMP(7);
+    }
+    if (works) chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore, bx, true, overflow, n_cand);
+    if (works && bx == 0) UTM_STAMP(8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every wave's stores are acknowledged before thread 0 reports in)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (works && bx >= UTM_MAX_CAND) __threadfence();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(&vs->arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == n_chain_blocks - 1;
+        if (last) __hip_atomic_store(&vs->arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (last) {
+        UTM_STAMP(9);
+        stage_acquire();  // (workgroup 0's IterState fields and list; the overflow workgroups' scores)
+        UTM_STAMP(10);
+        pick_body<0, true>(pa);
+        UTM_STAMP(11);
+    }
 }

@@ -300,6 +300,23 @@ static bool enqueue_candidates(utm_ctx *c, PickArgs a, bool pick_inside)
 {
     if (!a.cand) return false;
     a.early_pick = pick_inside ? 1 : 0;
+    static const int verify_env = tune_env("UTM_AF_VERIFY", 1);
+    if (pick_inside && verify_env) {
+        // the only shard: candidates, their addends, their chains and the pick as stages of ONE launch (k_verify)
+        const ChainFast &cf = c->chain_fast;
+        const unsigned n_fill = cf.counts ? (unsigned)cf.n_segs * (unsigned)cf.n_cand : 0u;
+        const unsigned seq_blocks = (std::max(1u, c->active_ub) + 1023) / 1024;
+        const dim3 grid(1 + n_fill + UTM_MAX_CAND + seq_blocks);
+        const unsigned launch_no = ++c->verify_launches;
+        const int n_chunks = (int)c->chunks.size();
+        if (c->af_mode == UTM_AF_F32)
+            hipLaunchKernelGGL(k_verify<float>, grid, dim3(1024), 0, c->stream, c->d_seq, n_chunks, c->d_st, c->d_cand, cf, c->d_act,
+                               c->d_cnt, c->d_fscore, a, c->d_vsync, launch_no, n_fill);
+        else
+            hipLaunchKernelGGL(k_verify<double>, grid, dim3(1024), 0, c->stream, c->d_seq, n_chunks, c->d_st, c->d_cand, cf, c->d_act,
+                               c->d_cnt, c->d_fscore, a, c->d_vsync, launch_no, n_fill);
+        return true;
+    }
     hipLaunchKernelGGL(k_cand, dim3(1), dim3(c->active_ub > 512 ? 1024 : 256), 0, c->stream, a);
     enqueue_chains(c, a, pick_inside);
     return pick_inside;
@@ -677,3 +694,13 @@ extern "C" int utm_set_profile(utm_ctx *c, int32_t on)
     else c->flags &= ~UTM_FLAG_PROFILE_EVENTS;
     return UTM_OK;
 }
+
+#ifdef UTM_DEBUG_STAMPS
+extern "C" int utm_dbg_verify_stamps(utm_ctx *c, uint64_t *out)
+{
+    VerifySync h;
+    HIP_TRY(copy_sync(c, &h, c->d_vsync, sizeof h, hipMemcpyDeviceToHost));
+    memcpy(out, h.stamps, sizeof h.stamps);
+    return UTM_OK;
+}
+#endif

@@ -119,6 +119,7 @@ extern "C" int utm_reset(utm_ctx *c)
     HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_fscore, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_arrivals, 0, 128, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_vsync, 0, sizeof(VerifySync), c->stream));  // (a run that ended on an error may have left counts behind)
     for (auto &ch : c->chunks) HIP_TRY(hipMemsetAsync(ch.covered, 0, ch.wp * 8, c->stream));
     // Samples that start out used cover their variants from the first iteration (select.py:36-39) -- on every
     // shard's covered replica, whoever owns the column: local columns are OR-ed in place; a peer's column is read
