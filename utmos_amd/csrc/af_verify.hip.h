@@ -157,6 +157,49 @@ __device__ __forceinline__ bool cand_list(const PickArgs &a, CandScratch &sc, bo
     return sc.chain_needed != 0;
 }
 
+// The pick of the only shard from the candidate list alone (1 <= n_c <= UTM_MAX_CAND entries, values final): mask /
+// weight / argmax as in pick_body, one lane of wave 0 per candidate; thread 0 decides.  OTHERS_WROTE: the list's
+// writers are other workgroups of the same launch (k_verify) -- it is read with agent-scope loads.
+template <bool OTHERS_WROTE>
+__device__ __forceinline__ void pick_among_candidates(const PickArgs &a, unsigned n_c, unsigned n_active, const Preloaded &pre)
+{
+    if (threadIdx.x >= 64) return;
+    Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
+    if (threadIdx.x < n_c) {
+        const unsigned b = threadIdx.x;
+        unsigned s, pos;
+        i64 c;
+        double v;
+        if (OTHERS_WROTE) {
+            s = __hip_atomic_load(&a.cand->samp[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pos = __hip_atomic_load(&a.cand->pos[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c = (i64)__hip_atomic_load(reinterpret_cast<const u64 *>(&a.cand->cnt[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&a.cand->val[b]), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+        } else {
+            s = a.cand->samp[b];
+            pos = a.cand->pos[b];
+            c = a.cand->cnt[b];
+            v = a.cand->val[b];
+        }
+        if (a.weights) v *= a.weights[a.first + s];
+        best = Cand{v, (i64)a.first + s, c, pos};
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const Cand other = shfl_cand(best, o);
+        if (better(other, best)) best = other;
+    }
+    if (threadIdx.x == 0) {
+        Rec *rc0 = rec_of(a, a.rank);
+        rc0->score = best.val;
+        rc0->idx = best.gidx;
+        rc0->new_count = best.cnt;
+        a.st->best_pos = best.pos;
+        decide_single(a, best, n_active, pre);
+    }
+}
+
 // ... and the pick when cand_list found that no chain is needed (early_pick).
 __device__ __forceinline__ void cand_pick(const PickArgs &a, CandScratch &sc, const Preloaded &pre)
 {
@@ -167,28 +210,7 @@ __device__ __forceinline__ void cand_pick(const PickArgs &a, CandScratch &sc, co
         pick_body<0>(a);
         return;
     }
-    if (threadIdx.x < 64) {  // the pick among the candidates: mask / weight / argmax as in pick_body, one lane each
-        Cand best{-__builtin_inf(), INT64_MAX, 0, 0};
-        if (threadIdx.x < n_c) {
-            const unsigned s = a.cand->samp[threadIdx.x];
-            double v = a.cand->val[threadIdx.x];
-            if (a.weights) v *= a.weights[a.first + s];
-            best = Cand{v, (i64)a.first + s, a.cand->cnt[threadIdx.x], a.cand->pos[threadIdx.x]};
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const Cand other = shfl_cand(best, o);
-            if (better(other, best)) best = other;
-        }
-        if (threadIdx.x == 0) {
-            Rec *rc0 = rec_of(a, a.rank);
-            rc0->score = best.val;
-            rc0->idx = best.gidx;
-            rc0->new_count = best.cnt;
-            st->best_pos = best.pos;
-            decide_single(a, best, n_active, pre);
-        }
-    }
+    pick_among_candidates<false>(a, n_c, n_active, pre);
 }
 
 __global__ __launch_bounds__(1024) void k_cand(PickArgs a)
@@ -409,15 +431,27 @@ __device__ __forceinline__ double chain_parallel(const ADDENDS &src, ParScratch 
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned total = src.total();
+    // a window's addends: UTM_PAR_E consecutive ones per thread
+    auto load_window = [&](unsigned base, double *a) {
+        const unsigned g0 = base + (unsigned)tid * UTM_PAR_E;
+        int seg = g0 < total ? src.first(g0) : 0;
+#pragma unroll
+        for (int j = 0; j < UTM_PAR_E; ++j) a[j] = g0 + j < total ? src.at(g0 + j, seg) : 0.0;
+    };
+    double a_next[UTM_PAR_E];
+    load_window(0, a_next);  // (in flight while the head is added up)
     // The first UTM_PAR_HEAD addends one by one (wave 0, registers only): a sum leaves a binade every few addends at
-    // its start, and every crossing would cost the scan a round of its own.
+    // its start, and every crossing would cost the scan a round of its own.  All of them are requested first.
     const unsigned head = total < UTM_PAR_HEAD ? total : UTM_PAR_HEAD;
     if (wave == 0) {
+        double hv[UTM_PAR_HEAD / 64];
+        int seg = 0;
+#pragma unroll
+        for (int r = 0; r < UTM_PAR_HEAD / 64; ++r) hv[r] = r * 64 + lane < (int)head ? src.at(r * 64 + lane, seg) : 0.0;
         double first = 0.0;
-        for (unsigned t = 0; t < head; t += 64) {
-            int seg = 0;
-            first = ordered_sum64(first, t + lane < head ? src.at(t + lane, seg) : 0.0);
-        }
+#pragma unroll
+        for (int r = 0; r < UTM_PAR_HEAD / 64; ++r)
+            if (r * 64 < (int)head) first = ordered_sum64(first, hv[r]);  // (wave uniform)
         if (lane == 0) sc.crossed = first;
     }
     __syncthreads();
@@ -425,14 +459,13 @@ __device__ __forceinline__ double chain_parallel(const ADDENDS &src, ParScratch 
     __syncthreads();
     for (unsigned base = 0; base < total; base += 1024u * UTM_PAR_E) {
         // this window's addends stay in registers until the window is used up: a round that ends at a binade crossing
-        // only moves `done` (addends in front of it count as 0 from then on) and re-runs the scans with the new unit
+        // only moves `done` (addends in front of it count as 0 from then on) and re-runs the scans with the new unit.
+        // The next window's are requested meanwhile.
         const unsigned g0 = base + (unsigned)tid * UTM_PAR_E;
         double a[UTM_PAR_E];
-        {
-            int seg = g0 < total ? src.first(g0) : 0;
 #pragma unroll
-            for (int j = 0; j < UTM_PAR_E; ++j) a[j] = g0 + j < total ? src.at(g0 + j, seg) : 0.0;
-        }
+        for (int j = 0; j < UTM_PAR_E; ++j) a[j] = a_next[j];
+        if (base + 1024u * UTM_PAR_E < total) load_window(base + 1024u * UTM_PAR_E, a_next);
         const unsigned end = total - base > 1024u * UTM_PAR_E ? base + 1024u * UTM_PAR_E : total;
         unsigned done = base > head ? base : head;  // addends [base, done) are in acc already
         while (done < end) {
@@ -749,6 +782,17 @@ __global__ __launch_bounds__(1024) void k_verify(const SeqChunk *__restrict__ ch
         if (!chain_needed) cand_pick(pa, sc, pre);
         return;
     }
+    // (what the pick will need from IterState: nothing of it changes before the pick itself, and here it loads while
+    // the workgroup waits; only the chain workgroups can end up making the pick)
+    Preloaded pre{0, 0, 0, 0};
+    unsigned n_active_pre = 0;
+    if (threadIdx.x == 0 && blockIdx.x > n_fill) {
+        n_active_pre = st->n_active;
+        pre.iter = st->iter;
+        pre.tot = st->tot;
+        pre.n_active_total = st->n_active_total;
+        pre.last_act = n_active_pre ? act[n_active_pre - 1] : 0;
+    }
     if (threadIdx.x == 0) {
         u64 w = 0;
         unsigned spin = 0;
@@ -815,9 +859,12 @@ __global__ __launch_bounds__(1024) void k_verify(const SeqChunk *__restrict__ ch
     __syncthreads();
     if (last) {
         UTM_STAMP(9);
-        stage_acquire();  // (workgroup 0's IterState fields and list; the overflow workgroups' scores)
-        UTM_STAMP(10);
-        pick_body<0, true>(pa);
+        if (overflow || pa.list_n) {
+            stage_acquire();  // (workgroup 0's IterState fields and list; the overflow workgroups' scores)
+            pick_body<0, true>(pa);
+        } else {
+            pick_among_candidates<true>(pa, (unsigned)n_cand, n_active_pre, pre);  // (the chains' values: agent-scope stores)
+        }
         UTM_STAMP(11);
     }
 }
