@@ -856,3 +856,65 @@ def test_parallel_chain_reproduces_sequential_float64_sums(dev, kind):
         for a in af[dense[:, got[0]]]:               # whichever sample won: its score is its own sequential sum
             want = want + float(a)
         assert float(got[2]).hex() == float(want).hex(), (kind, trial, n_var)
+
+
+@pytest.mark.parametrize("kind", ["f64", "f64_weights", "f32_beyond_exact", "f64_chunks"])
+def test_af_scores_finished_after_their_batch_are_the_reference_sums(dev, kind):
+    """Exact AF scores of unambiguous winners come from the log of newly-covered masks, one set of launches per batch
+    (af_defer.hip.h): however the run is cut into calls -- one call, single steps, uneven pieces that straddle the log's
+    64 slots -- every row's float64 score is the oracle's sequential sum, bit for bit, and the rows are the same."""
+    rng = np.random.default_rng(77)
+    n_var, n_samp = 60_000, 300
+    dense = ou.random_dense(rng, n_var, n_samp, density=0.02)
+    # distinct frequencies: nearly every winner is unambiguous, so nearly every score takes the deferred path
+    af = rng.uniform(1e-4, 0.5, size=n_var)
+    weights = None
+    bounds = [0, n_var]
+    if kind == "f64_weights":
+        weights = rng.uniform(0.5, 2.0, size=n_samp)
+    if kind == "f32_beyond_exact":
+        # a wide exponent range: the unit is that of the smallest value, and sums leave the range where float64 adds
+        # are exact (>= 2^53 units) -- estimates are inexact until enough is covered
+        af = np.exp2(rng.uniform(-12, -1, n_var)).astype(np.float32)
+        af[:40] = np.float32(2.0 ** -30) * (1 + rng.random(40).astype(np.float32))
+    if kind == "f64_chunks":
+        bounds = [0, 4097, 30_000, n_var]
+    cols = npo.pack_columns(dense)
+    state = np.ones(n_samp, np.uint8)
+    exp = ou.c_greedy(cols, n_var, state, weights, af)
+
+    def fresh():
+        m = dev.DeviceMatrix(n_samp)
+        for lo, hi in zip(bounds[:-1], bounds[1:]):
+            c = m.add_chunk(hi - lo)
+            m.upload_columns(c, npo.pack_columns(dense[lo:hi]))
+            m.set_af(c, af[lo:hi])
+        m.set_state(state)
+        m.set_weights(weights)
+        return m
+
+    def same(idx, new, score, upto):
+        assert list(idx) == exp[0][:upto].tolist() and list(new) == exp[1][:upto].tolist()
+        assert list(score) == exp[2][:upto].tolist()
+
+    with fresh() as m:                                   # one call
+        got = m.run(n_samp)
+        same(got[0], got[1], got[2], len(exp[0]))
+        st = m.stats()
+        assert st["af_fixed_point"] in (1, 2)
+        if kind == "f32_beyond_exact":
+            assert st["af_deferred_rows"] > 0, st
+        else:
+            assert st["af_deferred_rows"] > 0.5 * len(exp[0]), st
+            assert st["af_chained_iterations"] < 0.5 * len(exp[0]), st
+    with fresh() as m:                                   # uneven pieces: 1, 63, 64, 65, 7, the rest
+        idx, new, score = [], [], []
+        for piece in (1, 63, 64, 65, 7, n_samp):
+            got = m.run(piece)
+            idx += got[0].tolist(); new += got[1].tolist(); score += got[2].tolist()
+            same(idx, new, score, len(idx))             # (every call returns final scores for its own rows)
+        assert len(idx) == len(exp[0])
+    with fresh() as m:                                   # single steps
+        for it in range(40):
+            i, n, s = m.step()
+            assert (i, n, s) == (exp[0][it], exp[1][it], exp[2][it])
