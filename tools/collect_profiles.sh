@@ -26,6 +26,13 @@ done
 echo "== float64 AF (the reference's in-memory --af values)"
 python3 $R/bench.py --af --af-dtype f64 --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_bench.json 2>/dev/null
 python3 $R/bench.py --workload af64 --af-estimate-scores --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_cli_mode_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_af64_kt -- python3 $R/bench.py --workload af64 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline-pass --pmc-traffic off > /dev/null 2>&1 || exit 1
+cut -c1-220 $(find $R/gpurun_out/prof_${tag}_af64_kt -name "*kernel_stats.csv") > $out/${tag}_af64_kernel_stats.csv
+python3 $R/tools/kernel_dist.py $R/gpurun_out/prof_${tag}_af64_kt k_verify > $out/${tag}_af64_k_verify_durations.txt 2>&1
+find $R/gpurun_out/prof_${tag}_af64_kt -name "*.csv" -size +3M -delete
+echo "== float64 / float32 AF at chr22 size (1,103,547 x 2,504)"
+python3 $R/bench.py --n-var 1103547 --af --af-dtype f64 --steps 3 --warmup 1 --no-cpu-baseline --no-also --pmc-traffic off > $out/${tag}_chr22size_af64_bench.json 2>/dev/null
+python3 $R/bench.py --n-var 1103547 --af --af-dtype f32 --steps 3 --warmup 1 --no-cpu-baseline --no-also --pmc-traffic off > $out/${tag}_chr22size_af32_bench.json 2>/dev/null
 echo "== RCCL protocol overhead with a 1-rank communicator (collectives degenerate; launch and sync costs real)"
 for x in rccl rccl-allreduce; do
   python3 $R/bench.py --force-comm --exchange $x --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off --no-sharded-check > $out/${tag}_cfg2_one_rank_${x}_bench.json 2>/dev/null
