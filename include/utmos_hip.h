@@ -32,6 +32,9 @@
  *   UTM_NT_LOADS (auto)       non-temporal column loads on/off              UTM_NT_MIN_MB (512) matrix size from which they are used
  *   UTM_FUSE_PICK (1)         pick inside the scoring launch (one shard or mailbox exchange, integer scores)
  *   UTM_CHAIN_PICK (1)        AF with candidate chains: pick inside the chain launch (one shard)
+ *   UTM_AF_VERIFY (1)         ... and candidates, compaction, chains and pick as stages of ONE launch (one shard)
+ *   UTM_AF_DEFER (1)          AF, one shard: exact float64 scores of unambiguous winners are finished per batch from a
+ *                             log of newly-covered masks (needs 64 columns + 8 bytes per variant of HBM; 0: chained on the spot)
  *   UTM_PICK_THREADS (auto)   threads of the stand-alone k_pick             UTM_BATCH (256; AF 64) iterations between host syncs
  *   UTM_AF_STEPS (16), UTM_AF_SWITCH (0.2), UTM_AF_TARGET_WGS (16384)       AF kernels: tile, dense->streaming switch, grid
  *   UTM_DECR_FIRST_BATCH (8), UTM_DECR_INTERLEAVED (1)                      decremental mode: first batch size, second copy on/off
