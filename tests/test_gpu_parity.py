@@ -918,3 +918,52 @@ def test_af_scores_finished_after_their_batch_are_the_reference_sums(dev, kind):
         for it in range(40):
             i, n, s = m.step()
             assert (i, n, s) == (exp[0][it], exp[1][it], exp[2][it])
+
+
+def _af_run_worker(seed, env, q):
+    """One whole float64-AF selection in a process of its own (spawned): (seed, rows, scores as hex)."""
+    import os
+    os.environ.update(env)
+    import numpy as np
+    import oracle_util as ou
+    from oracle_util import npo
+    from utmos_amd import device
+    rng = np.random.default_rng(seed)
+    n_var, n_samp = 200_000, 260
+    dense = ou.random_dense(rng, n_var, n_samp)
+    af = np.round(rng.uniform(1, 40, size=n_var)) / (2.0 * n_samp)      # few distinct values: near-ties, chains on the spot
+    cols = npo.pack_columns(dense)
+    try:
+        with device.DeviceMatrix(n_samp) as m:
+            c = m.add_chunk(n_var)
+            m.upload_columns(c, cols)
+            m.set_af(c, af)
+            got = m.run(n_samp)
+            st = m.stats()
+        exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8), None, af)
+        ok = got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
+        q.put((seed, ok, st["af_chained_iterations"], st["af_deferred_rows"], None))
+    except Exception as e:      # noqa: BLE001 -- reported to the parent, which fails the test
+        q.put((seed, False, -1, -1, repr(e)))
+
+
+@pytest.mark.parametrize("env", [{}, {"UTM_AF_VERIFY": "0"}, {"UTM_AF_DEFER": "0"}, {"UTM_AF_VERIFY": "0", "UTM_AF_DEFER": "0"}],
+                         ids=["default", "three-launch verification", "chained on the spot", "both off"])
+def test_af_verification_forms_agree_while_processes_share_the_gpu(dev, env):
+    """The one-launch verification (k_verify) has workgroups waiting for other workgroups of the same launch: three
+    processes run such loops on the one GPU at the same time (their launches interleave on the CUs) and every one of
+    them still reproduces the oracle bit for bit -- as do the separate-launch and chained-on-the-spot forms that
+    shards of a multi-GPU run use (selected here through the library's environment switches)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_af_run_worker, args=(100 + r, env, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for seed, ok, chained, deferred, err in res:
+        assert err is None and ok, (seed, err)
+        assert chained > 0                                   # the data does force chains
+        assert (deferred > 0) == (env.get("UTM_AF_DEFER") != "0")
