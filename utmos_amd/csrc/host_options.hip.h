@@ -228,10 +228,15 @@ static int build_af_tables(utm_ctx *c)
         const size_t need = (size_t)UTM_DEFER_SLOTS * c->col_words * 8 + slots * 8 + (size_t)UTM_DEFER_SLOTS * n * 12 + 8;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         if (defer_env && cap && c->d_segs && c->n_local == c->n_total && slots < 0xFFFF0000ull && need <= free_b / 4) {
-            HIP_TRY(hipMalloc(&c->d_newly_log, (size_t)UTM_DEFER_SLOTS * c->col_words * 8));
-            HIP_TRY(hipMalloc(&c->d_defer_vals, slots * 8));
-            HIP_TRY(hipMalloc(&c->d_defer_counts, (size_t)UTM_DEFER_SLOTS * n * 4));
-            HIP_TRY(hipMalloc(&c->d_defer_offs, ((size_t)UTM_DEFER_SLOTS * n + 1) * 8));
+            const bool ok = hipMalloc(&c->d_newly_log, (size_t)UTM_DEFER_SLOTS * c->col_words * 8) == hipSuccess &&
+                            hipMalloc(&c->d_defer_vals, slots * 8) == hipSuccess &&
+                            hipMalloc(&c->d_defer_counts, (size_t)UTM_DEFER_SLOTS * n * 4) == hipSuccess &&
+                            hipMalloc(&c->d_defer_offs, ((size_t)UTM_DEFER_SLOTS * n + 1) * 8) == hipSuccess;
+            if (!ok) {  // all four or none (defer_active looks at the log alone)
+                (void)hipGetLastError();
+                (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
+                c->d_newly_log = nullptr; c->d_defer_counts = nullptr; c->d_defer_offs = nullptr; c->d_defer_vals = nullptr;
+            }
         }
     }
     c->dirty_tables = false;
