@@ -73,6 +73,8 @@ def parse():
     p.add_argument("--decremental", action="store_true",
                    help="SURVEY 8f-4 shortcut (exact, reads far fewer bytes): reported separately, never the default")
     p.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip rank 0's single-GPU re-run and comparison")
+    p.add_argument("--rccl-leg-timeout", type=float, default=240.0,
+                   help="N > 1: seconds the additional RCCL measurements may take before the line is printed without them")
     p.add_argument("--exchange", choices=["auto", "mailboxes", "rccl", "rccl-allreduce", "both"], default="both",
                    help="N > 1: both = headline through the default exchange (mailboxes, else RCCL) and the same steps again "
                         "through RCCL (also_exchange); auto / mailboxes / rccl = that one only")
@@ -310,6 +312,32 @@ def workload_label(spec):
             f"{'all' if spec['select'] < 0 else k}{(', --af ' + spec['af_dtype']) if spec['af'] else ''}")
 
 
+def headline_line(args, world, n_total, exchange, exchange_note, final_stats, st, res, head, roofline):
+    """The JSON line's fields that the headline measurement alone decides (the legs behind it fill in the rest)."""
+    return {
+        "metric": METRIC, "value": head["value"], "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": (args.af_dtype + "+u64") if args.af else "u64", "data": "synthetic",
+        "config": {"workload": head["workload"], "n_var": args.n_var, "n_samp": n_total,
+                   "iterations_per_step": head["iterations_per_step"], "tot_captured": head["tot_captured"], "chunks": head["chunks"],
+                   "seed": args.seed, "sharding": f"sample axis over {world} GPU(s)" if world > 1 else "none",
+                   "generator_s": head["generator_s"], "af_verified_parallel": st["af_fixed_point"] if args.af else None,
+                   **{k: head[k] for k in ("af_chained_iterations", "af_deferred_rows") if k in head}},
+        "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": final_stats["rccl_ranks"] if exchange.startswith("rccl") else None,
+        "p2p_replica_bytes": final_stats["p2p_replica_bytes"] if world > 1 else None,
+        "also_exchange": None,
+        "scoring": "decremental after the first passes (bytes = what this variant actually reads; NOT the brute-force "
+                   "roofline metric)" if args.decremental else "brute force: every selectable column re-read every iteration",
+        "decremental_iterations_per_step": st["decr_iterations"] if args.decremental else 0,
+        "decremental_interleaved_copy_bytes": st["decr_interleaved_bytes"] if args.decremental else 0,
+        "brute_force_equivalent_gbps": st["brute_force_bytes"] * world * args.steps / res["elapsed"] / 1e9,
+        "hbm_gbps_whole_loop": head["hbm_gbps_whole_loop"], "hbm_frac_whole_loop": head["hbm_frac_whole_loop"],
+        "device_loop_ms_per_step": head["device_loop_ms_per_step"],
+        "sharded_rows_match_single_gpu": None,
+        "roofline": roofline, "cpu_baseline": None, "cpu_bitset_baseline": None, "also": None,
+    }
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
@@ -399,9 +427,31 @@ def main():
     if not args.no_roofline_pass and not args.decremental:   # the roofline object describes the brute-force kernel only
         roofline = roofline_pass(m, k_sel, args.af, rank)
 
-    # N > 1: the same steps again through north_star's RCCL protocol, measured beside the default exchange
+    # N > 1: the same steps again through north_star's RCCL protocol, measured beside the default exchange.  These legs
+    # bring up a communicator that the headline did not need: should that, or a collective, hang on some node, every
+    # rank leaves after --rccl-leg-timeout seconds and rank 0 still prints the headline it has already measured.
     also_exchange = None
+    early = {"line": None}
+    watchdog = None
+    real_stdout = os.dup(1)
     if world > 1 and args.exchange == "both" and exchange == "mailboxes":
+        import threading
+
+        def give_up():
+            if rank == 0 and early["line"] is not None:
+                early["line"]["also_exchange"] = {"error": f"the RCCL legs did not finish within {args.rccl_leg_timeout:.0f} s (communicator set-up "
+                                                           f"or a collective hung); the headline was measured through {exchange} before them"}
+                # (straight to the process's own stdout: while a communicator is being set up, fd 1 is parked on stderr
+                # to keep RCCL's banner out of the line -- device.comm_init)
+                os.write(real_stdout, (json.dumps(early["line"]) + "\n").encode())
+            os._exit(0 if early["line"] is not None or rank != 0 else 3)
+
+        if rank == 0:
+            early["line"] = headline_line(args, world, n_total, exchange, exchange_note, m.stats(), st, res,
+                                          summarize(spec, workload_label(spec), world, args.steps, res, roofline, t_gen), roofline)
+        watchdog = threading.Timer(args.rccl_leg_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         m.p2p_use_mailboxes(False)
         err = None
         try:
@@ -428,6 +478,8 @@ def main():
         else:
             also_exchange = {"rccl": {"error": f"RCCL communicator unavailable on some rank ({err})"}}
         m.p2p_use_mailboxes(True)             # back to the headline's exchange for the check below
+        sync_max(0.0)
+        watchdog.cancel()
 
     # PMC traffic cannot be read from inside the process: two counter passes in child processes (N = 1), else the
     # passes recorded under profiles/ for the default configurations (tools/summarize_profile.py)
@@ -487,28 +539,9 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu, bitset = cpu_baseline(args, device, idx)
 
-    line = {
-        "metric": METRIC, "value": head["value"], "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": (args.af_dtype + "+u64") if args.af else "u64", "data": "synthetic",
-        "config": {"workload": head["workload"], "n_var": args.n_var, "n_samp": n_total,
-                   "iterations_per_step": head["iterations_per_step"], "tot_captured": head["tot_captured"], "chunks": head["chunks"],
-                   "seed": args.seed, "sharding": f"sample axis over {world} GPU(s)" if world > 1 else "none",
-                   "generator_s": head["generator_s"], "af_verified_parallel": st["af_fixed_point"] if args.af else None,
-                   **{k: head[k] for k in ("af_chained_iterations", "af_deferred_rows") if k in head}},
-        "exchange": exchange, "exchange_note": exchange_note, "rccl_ranks": final_stats["rccl_ranks"] if exchange.startswith("rccl") else None,
-        "p2p_replica_bytes": final_stats["p2p_replica_bytes"] if world > 1 else None,
-        "also_exchange": also_exchange,
-        "scoring": "decremental after the first passes (bytes = what this variant actually reads; NOT the brute-force "
-                   "roofline metric)" if args.decremental else "brute force: every selectable column re-read every iteration",
-        "decremental_iterations_per_step": st["decr_iterations"] if args.decremental else 0,
-        "decremental_interleaved_copy_bytes": st["decr_interleaved_bytes"] if args.decremental else 0,
-        "brute_force_equivalent_gbps": st["brute_force_bytes"] * world * args.steps / res["elapsed"] / 1e9,
-        "hbm_gbps_whole_loop": head["hbm_gbps_whole_loop"], "hbm_frac_whole_loop": head["hbm_frac_whole_loop"],
-        "device_loop_ms_per_step": head["device_loop_ms_per_step"],
-        "sharded_rows_match_single_gpu": sharded_check,
-        "roofline": roofline, "cpu_baseline": cpu, "cpu_bitset_baseline": bitset, "also": also,
-    }
+    line = headline_line(args, world, n_total, exchange, exchange_note, final_stats, st, res, head, roofline)
+    line.update({"also_exchange": also_exchange, "sharded_rows_match_single_gpu": sharded_check, "cpu_baseline": cpu,
+                 "cpu_bitset_baseline": bitset, "also": also})
     print(json.dumps(line))
 
 
