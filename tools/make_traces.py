@@ -294,6 +294,21 @@ def main():
         for label, argv in (("mid_int", ["-c", "-1"]), ("mid_af", ["-c", "-1", "--af"])):
             tsv, tr = run_cli(sel, tmp, [m_mid], argv)
             save(label, {"kind": "cli", "inputs": ["mid"], "argv": argv, "tsv": tsv, **tr})
+        # ... with AF, a weight on every third sample (positive, all different) and a few samples excluded: weighted
+        # float64 scores at a width where the device's candidate lists, chains and deferred scores all come into play
+        rng_w = np.random.default_rng(62)
+        names_mid = [x.decode() for x in m_mid["samples"]]
+        wl_mid = [(names_mid[i], float(np.round(rng_w.uniform(0.25, 4.0), 6))) for i in range(0, len(names_mid), 3)]
+        with open(wtxt, "w") as fh:
+            fh.write("".join(f"{k}\t{v!r}\n" for k, v in wl_mid))
+        excl = ",".join(names_mid[i] for i in (5, 77, 700, 1499))
+        argv = ["-c", "-1", "--af", "--weights", wtxt, "--exclude", excl]
+        tsv, tr = run_cli(sel, tmp, [m_mid], argv)
+        save("mid_af_weights_exclude", {"kind": "cli", "inputs": ["mid"], "weights": wl_mid,
+                                        "argv": ["-c", "-1", "--af", "--weights", "<weights>", "--exclude", excl], "tsv": tsv, **tr})
+        # ... and the hdf5 flavour of the AF values (float32) for a fixed number of picks
+        tsv, tr = run_direct(sel, tmp, [m_mid], True, True, 300)
+        save("mid_af32_c300", {"kind": "direct", "inputs": ["mid"], "af": True, "af_dtype": "f32", "count": 300, "tsv": tsv, **tr})
 
         # ---- 5. --count resolution as run_selection applies it (select.py:157-159)
         table = []
