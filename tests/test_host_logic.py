@@ -384,3 +384,45 @@ def test_connect_shards_order_mailboxes_then_rccl_then_error():
     one = _EchoTransport()
     one.world = 1
     assert connect_shards(_ScriptedShard(), one, None) == "none"
+
+
+def test_vcf_reader_fast_path_equals_the_cell_walk(tmp_path):
+    """Records whose sample columns are all `a|b` / `a/b` with one-character alleles are parsed with one reshape; every
+    other shape (more FORMAT fields, haploid calls, two-digit alleles) falls back to the cell walk.  Both give the
+    same presence bits and allele frequencies."""
+    import gzip
+    import time
+    from utmos_amd.vcfio import read_vcf
+    rng = np.random.default_rng(8)
+    n_samp = 301
+    names = [f"S{i:04d}" for i in range(n_samp)]
+    lines = ["##fileformat=VCFv4.2\n", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n"]
+    for v in range(400):
+        n_alt = int(rng.integers(1, 4))
+        alt = ",".join("ACGT"[i] for i in range(n_alt))
+        kind = v % 8
+        cells = []
+        for _ in range(n_samp):
+            a = [str(x) if x >= 0 else "." for x in rng.integers(-1, n_alt + 1, 2)]
+            sep = "|" if rng.random() < 0.5 else "/"
+            cell = a[0] + sep + a[1]
+            if kind == 5 and rng.random() < 0.1:
+                cell = a[0]                                  # haploid
+            if kind == 6 and rng.random() < 0.05:
+                cell = "10" + sep + a[1]                     # an allele index this record does not have, two digits
+            if kind == 7:
+                cell += ":" + str(int(rng.integers(0, 99)))  # GT:DP
+            cells.append(cell)
+        fmt = "GT:DP" if kind == 7 else "GT"
+        lines.append(f"1\t{100 + v}\t.\tA\t{alt}\t.\t.\t.\t{fmt}\t" + "\t".join(cells) + "\n")
+    path = str(tmp_path / "mixed.vcf.gz")
+    with gzip.open(path, "wt") as fh:
+        fh.writelines(lines)
+    t0 = time.perf_counter()
+    fast = read_vcf(path)
+    t1 = time.perf_counter()
+    slow = read_vcf(path, fast=False)
+    t2 = time.perf_counter()
+    assert (fast["GT"] == slow["GT"]).all() and (fast["AF"] == slow["AF"]).all() and (fast["samples"] == slow["samples"]).all()
+    assert fast["GT"].shape == (400, (n_samp + 7) // 8) and fast["GT"].any()
+    assert (t1 - t0) < (t2 - t1)                                # five records in eight take the reshape
