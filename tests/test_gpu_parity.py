@@ -252,10 +252,12 @@ def test_multi_chunk_equals_single_chunk(dev):
     check_run(dev, dense, chunks=bounds, af=af64)
 
 
+@pytest.mark.parametrize("decremental", [True, False])
 @pytest.mark.parametrize("af_kind", [None, "f32", "f64"])
-def test_step_peek_and_covered(dev, af_kind):
+def test_step_peek_and_covered(dev, af_kind, decremental):
     """step / peek_scores / covered interleaved: peeks and covered reads apply the pending winner outside the loop,
-    so the persistent AF accumulators (and the decremental counts) must be rebuilt afterwards."""
+    so the persistent AF accumulators (and the decremental counts) must be rebuilt afterwards -- and, without the
+    decremental mode, the deferred exact AF scores have to survive full passes turning up between delta passes."""
     rng = np.random.default_rng(13)
     n_var, n_samp = 5000, 40
     dense = ou.random_dense(rng, n_var, n_samp)
@@ -268,13 +270,22 @@ def test_step_peek_and_covered(dev, af_kind):
     with make_matrix(dev, cols, n_var) as m:
         if af is not None:
             m.set_af(0, af)
-        m.set_decremental(True, 1.0)
+        if decremental:
+            m.set_decremental(True, 1.0)
         covered = np.zeros(cols.shape[1], np.uint64)
-        for it in range(8):
+        for it in range(12):
             best, cnt, sc = ou.c_score(cols, n_var, state, af=af)
             if it % 2 == 0:
                 counts, scores = m.peek_scores()
                 assert counts.tolist() == cnt.tolist() and scores.tolist() == sc.tolist()
+            if it in (5, 9):                                  # two rows in one call between the single steps
+                idx2, new2, sc2 = m.run(2)
+                for j in range(2):
+                    best, cnt, sc = ou.c_score(cols, n_var, state, af=af)
+                    assert (idx2[j], new2[j], sc2[j]) == (best, cnt[best], sc[best])
+                    state[best] = 0
+                    covered |= cols[best]
+                continue
             got = m.step()
             assert got is not None and got[0] == best and got[1] == cnt[best] and got[2] == sc[best]
             state[best] = 0
