@@ -10,8 +10,8 @@ A *step* is one full `select all` run of the greedy loop (utmos/select.py:69-112
         bench.py --gpus N --steps K --warmup W          # one rank per GPU; samples sharded over the ranks
 
 N = 1, default workload: after the headline the other single-GPU BASELINE configurations run one step each (cfg3
-`--af` float32, cfg1 chr22-sized, one rank's share of cfg4 for 20 iterations, cfg5's 156 GB for 10) and are
-attached under `also`, each with its own it/s, bytes and roofline fraction.
+`--af` float32 and the same with the reference's in-memory float64 values, cfg1 chr22-sized, one rank's share of cfg4
+for 20 iterations, cfg5's 156 GB for 10) and are attached under `also`, each with its own it/s, bytes and roofline fraction.
 
 N > 1: the same 10M x 2,504 problem is sharded over the sample axis (strong scaling).  The line says how the shards
 met every iteration (`exchange`, `rccl_ranks`, `p2p_replica_bytes`); the headline is the default exchange (device
@@ -46,7 +46,7 @@ WORKLOADS = {
     "cfg5": ("500M x 2,504 in chunks of 50M, first 10 iterations",
              dict(n_var=500_000_000, n_samp=2504, select=10, chunk_vars=50_000_000)),
 }
-ALSO = ("cfg3", "cfg1", "cfg4rank", "cfg5")       # attached to the default single-GPU line, one step each
+ALSO = ("cfg3", "af64", "cfg1", "cfg4rank", "cfg5")   # attached to the default single-GPU line, one step each
 
 
 def parse():
@@ -529,7 +529,7 @@ def main():
                 m2, t2 = build_matrix(device, s2, dev_index)
                 with m2:
                     k2 = select_count(s2)
-                    r2 = timed_steps(m2, k2, 1, 1 if name in ("cfg1", "cfg3") else 0, lambda v: v)
+                    r2 = timed_steps(m2, k2, 1, 1 if name in ("cfg1", "cfg3", "af64") else 0, lambda v: v)
                     roof2 = roofline_pass(m2, k2, s2["af"])
                 also[name] = summarize(s2, WORKLOADS[name][0], 1, 1, r2, roof2, t2)
             except device.nat.NativeError as exc:      # e.g. a GPU with less HBM than the 156 GB of cfg5
