@@ -33,6 +33,7 @@
  *   UTM_FUSE_PICK (1)         pick inside the scoring launch (one shard or mailbox exchange, integer scores)
  *   UTM_CHAIN_PICK (1)        AF with candidate chains: pick inside the chain launch (one shard)
  *   UTM_AF_VERIFY (1)         ... and candidates, compaction, chains and pick as stages of ONE launch (one shard)
+ *   UTM_AF_RECORD (1)         AF: a chain's float64 sum stays on record per sample for as long as the sample's count does not change
  *   UTM_AF_DEFER (1)          AF, one shard: exact float64 scores of unambiguous winners are finished per batch from a
  *                             log of newly-covered masks (needs 64 columns + 8 bytes per variant of HBM; 0: chained on the spot)
  *   UTM_PICK_THREADS (auto)   threads of the stand-alone k_pick             UTM_BATCH (256; AF 64) iterations between host syncs

@@ -16,8 +16,10 @@
 // the argmax -- and k_chain recomputes exactly those few with the reference's sequential chain.
 // Result: bit-identical winner and score, with the bulk of the work order independent.
 // ------------------------------------------------------------------------------------------------
+// est_exact: the ESTIMATE is the reference's sum (what IterState::all_exact is about); exact: the value returned in
+// `est` is -- the estimate, or a sum a chain produced earlier for this very count (PickArgs::known_*).
 __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c, double &lo, double &hi, double &est,
-                                            bool &exact)
+                                            bool &exact, bool &est_exact)
 {
     const i64 e = a.afsum[s];
     est = (double)e * a.af_scale;
@@ -29,6 +31,11 @@ __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c
     } else {
         exact = (e < (1ll << 53) && !a.af_trunc) || c == 0;
         rel = 1.05 * ((double)c * 1.1102230246251565e-16 + 1.2e-16);
+    }
+    est_exact = exact;
+    if (!exact && a.known_cnt && a.known_cnt[s] == c) {
+        est = a.known_val[s];
+        exact = true;
     }
     double l = exact ? est : est - rel * est, h = exact ? est : top + rel * top;
     if (l < 0.0) l = 0.0;
@@ -70,7 +77,7 @@ __device__ __forceinline__ bool cand_list(const PickArgs &a, CandScratch &sc, bo
     unsigned rs[UTM_CAND_R];
     u64 rc[UTM_CAND_R];
     double rlo[UTM_CAND_R], rhi[UTM_CAND_R], rest[UTM_CAND_R];
-    bool rex[UTM_CAND_R];
+    bool rex[UTM_CAND_R], rxx[UTM_CAND_R];  // value exact / estimate exact
     double best_lo = -__builtin_inf();
     if (in_regs) {
 #pragma unroll
@@ -88,16 +95,16 @@ __device__ __forceinline__ bool cand_list(const PickArgs &a, CandScratch &sc, bo
             const unsigned i = threadIdx.x + r * blockDim.x;
             rlo[r] = rhi[r] = -__builtin_inf();
             rest[r] = 0.0;
-            rex[r] = true;
-            if (i < n_active) af_interval(a, rs[r], rc[r], rlo[r], rhi[r], rest[r], rex[r]);
+            rex[r] = rxx[r] = true;
+            if (i < n_active) af_interval(a, rs[r], rc[r], rlo[r], rhi[r], rest[r], rex[r], rxx[r]);
             best_lo = rlo[r] > best_lo ? rlo[r] : best_lo;
         }
     } else {
         for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
             const unsigned s = a.act[i];
             double lo, hi, est;
-            bool exact;
-            af_interval(a, s, a.cnt[s], lo, hi, est, exact);
+            bool exact, est_exact;
+            af_interval(a, s, a.cnt[s], lo, hi, est, exact, est_exact);
             best_lo = lo > best_lo ? lo : best_lo;
         }
     }
@@ -110,8 +117,8 @@ __device__ __forceinline__ bool cand_list(const PickArgs &a, CandScratch &sc, bo
     __syncthreads();
     best_lo = sc.wmax[0];
     for (unsigned w = 1; w < (blockDim.x >> 6); ++w) best_lo = fmax(best_lo, sc.wmax[w]);
-    auto consider = [&](unsigned i, unsigned s, u64 c, double hi, double est, bool exact) {
-        if (!exact) sc.any_inexact = 1;
+    auto consider = [&](unsigned i, unsigned s, u64 c, double hi, double est, bool exact, bool est_exact) {
+        if (!est_exact) sc.any_inexact = 1;
         if (hi >= best_lo) {
             const unsigned slot = atomicAdd(&sc.n_c, 1u);
             if (slot < UTM_MAX_CAND) {
@@ -128,16 +135,16 @@ __device__ __forceinline__ bool cand_list(const PickArgs &a, CandScratch &sc, bo
 #pragma unroll
         for (int r = 0; r < UTM_CAND_R; ++r) {
             const unsigned i = threadIdx.x + r * blockDim.x;
-            if (i < n_active) consider(i, rs[r], rc[r], rhi[r], rest[r], rex[r]);
+            if (i < n_active) consider(i, rs[r], rc[r], rhi[r], rest[r], rex[r], rxx[r]);
         }
     } else {
         for (unsigned i = threadIdx.x; i < n_active; i += blockDim.x) {
             const unsigned s = a.act[i];
             const u64 c = a.cnt[s];
             double lo, hi, est;
-            bool exact;
-            af_interval(a, s, c, lo, hi, est, exact);
-            consider(i, s, c, hi, est, exact);
+            bool exact, est_exact;
+            af_interval(a, s, c, lo, hi, est, exact, est_exact);
+            consider(i, s, c, hi, est, exact, est_exact);
         }
     }
     __syncthreads();
@@ -563,7 +570,7 @@ template <typename AF_T>
 __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks, int n_chunks, const IterState *__restrict__ st,
                                             CandBuf *__restrict__ cand, const ChainFast &f, const unsigned *__restrict__ act,
                                             u64 *__restrict__ cnt, double *__restrict__ fscore, unsigned bx, bool need_chain,
-                                            bool overflow, int n_cand);
+                                            bool overflow, int n_cand, u64 *__restrict__ known_cnt, double *__restrict__ known_val);
 
 // PICK: the iteration's pick (k_pick<0>'s body) runs in whichever workgroup of this launch finishes last -- one launch
 // less per iteration wherever candidates are verified (float64 AF: every iteration).  Arrival is one returning atomic
@@ -576,7 +583,8 @@ __global__ __launch_bounds__(1024) void k_chain(const SeqChunk *__restrict__ chu
 {
     if (st->done) return;  // (uniform over the launch: nobody arrives, nobody picks)
     if (PICK && pa.early_pick && !st->need_chain) return;  // (... and so is this: k_cand has made the pick already)
-    chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore, blockIdx.x, st->need_chain != 0, st->cand_overflow != 0, st->n_cand);
+    chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore, blockIdx.x, st->need_chain != 0, st->cand_overflow != 0, st->n_cand,
+                      pa.known_cnt, pa.known_val);
     if (PICK) {
         __shared__ int last;
         __syncthreads();
@@ -601,7 +609,7 @@ template <typename AF_T>
 __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks, int n_chunks, const IterState *__restrict__ st,
                                             CandBuf *__restrict__ cand, const ChainFast &f, const unsigned *__restrict__ act,
                                             u64 *__restrict__ cnt, double *__restrict__ fscore, unsigned bx, bool need_chain,
-                                            bool overflow, int n_cand)
+                                            bool overflow, int n_cand, u64 *__restrict__ known_cnt, double *__restrict__ known_val)
 {
     __shared__ double buf[UTM_CHAIN_CAP];
     __shared__ unsigned wtot[2][16];  // double buffered: one barrier per empty round
@@ -614,6 +622,16 @@ __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks,
     }
     if (overflow || (int)bx >= n_cand) return;
     const unsigned s = cand->samp[bx];
+    const u64 s_cnt = (u64)cand->cnt[bx];
+    // (a sum on record for this count: k_cand has put it into the list already)
+    if (known_cnt && known_cnt[s] == s_cnt) return;
+    auto put_on_record = [&](double sum) {  // thread 0
+        __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[bx]), __builtin_bit_cast(u64, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (known_cnt) {
+            known_val[s] = sum;
+            known_cnt[s] = s_cnt;
+        }
+    };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (f.counts && n_cand <= f.n_cand && f.n_segs <= UTM_PAR_MAX_SEGS) {
         // k_chain_fill compacted this candidate's addends per segment: if every segment fitted its region, all 1024
@@ -647,7 +665,7 @@ __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks,
             __syncthreads();
             const SegmentedAddends src{f.vals + (size_t)bx * f.n_segs * f.seg_cap, f.seg_cap, offs, f.n_segs};
             const double sum = chain_parallel(src, sc);
-            if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[bx]), __builtin_bit_cast(u64, sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) put_on_record(sum);
             return;
         }
         __syncthreads();  // (dense: the one-workgroup chain below reuses buf)
@@ -709,7 +727,7 @@ __device__ __forceinline__ void chain_block(const SeqChunk *__restrict__ chunks,
             }
         }
     }
-    if (tid == 0) __hip_atomic_store(reinterpret_cast<u64 *>(&cand->val[bx]), __builtin_bit_cast(u64, acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) put_on_record(acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -845,7 +863,7 @@ __global__ __launch_bounds__(1024) void k_verify(const SeqChunk *__restrict__ ch
         stage_acquire();  // the candidate list, IterState's fields, the compacted addends
         if (bx == 0) UTM_STAMP(7);
     }
-    if (works) chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore, bx, true, overflow, n_cand);
+    if (works) chain_block<AF_T>(chunks, n_chunks, st, cand, f, act, cnt, fscore, bx, true, overflow, n_cand, pa.known_cnt, pa.known_val);
     if (works && bx == 0) UTM_STAMP(8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every wave's stores are acknowledged before thread 0 reports in)
     __syncthreads();

@@ -116,6 +116,10 @@ struct PickArgs {
     int af_is_f64;   // the estimate sums float32-rounded values of float64 AFs
     int af_trunc;    // the fixed-point unit is coarser than the smallest AF's last bit: every addend may lose < 1 unit
     int af_skip_single;  // a single candidate is the winner whatever its exact sum is: skip its chain, report the estimate
+    // float64 sums the chains have produced, by sample, with the count each belongs to: a sample's uncovered set only
+    // shrinks, so while its count is the one on record its sequential sum is the one on record too -- no chain needed
+    u64 *known_cnt;      // n_local (UINT64_MAX: nothing on record), or nullptr
+    double *known_val;
     int early_pick;      // the only shard: k_cand also makes the pick when no chain is needed (the chain launches behind it
                          // then return at once; when one is needed, their last workgroup picks)
     Rec *recs;       // every shard's record of the current iteration, recs[rank]

@@ -119,7 +119,8 @@ extern "C" int utm_reset(utm_ctx *c)
     HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_fscore, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_arrivals, 0, 128, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_vsync, 0, sizeof(VerifySync), c->stream));  // (a run that ended on an error may have left counts behind)
+    HIP_TRY(hipMemsetAsync(c->d_vsync, 0, sizeof(VerifySync), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_known_cnt, 0xFF, (size_t)c->n_local * 8, c->stream));  // (a run that ended on an error may have left counts behind)
     for (auto &ch : c->chunks) HIP_TRY(hipMemsetAsync(ch.covered, 0, ch.wp * 8, c->stream));
     // Samples that start out used cover their variants from the first iteration (select.py:36-39) -- on every
     // shard's covered replica, whoever owns the column: local columns are OR-ed in place; a peer's column is read
@@ -245,6 +246,9 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     // come later, from the deferred launches
     a.af_skip_single = ((!c->af_exact_scores || defer_active(c)) && c->n_local == c->n_total) ? 1 : 0;
     a.early_pick = 0;  // (enqueue_candidates decides)
+    static const int record_env = tune_env("UTM_AF_RECORD", 1);
+    a.known_cnt = (a.cand && record_env) ? c->d_known_cnt : nullptr;
+    a.known_val = c->d_known_val;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
     a.remote_winner_test = c->remote_winner_test ? 1 : 0;
     a.res_idx = c->d_res_idx;

@@ -312,6 +312,7 @@ __device__ __forceinline__ void pick_body(const PickArgs &a)
             if (a.zero_after) a.afsum[s] = 0;
             if (a.afsum_mirror) a.afsum_mirror[s] = q;
             v = (double)q * a.af_scale;  // exact: q < 2^53 whenever this value is used, and the scale is a power of two
+            if (a.known_cnt && a.known_cnt[s] == c) v = a.known_val[s];  // ... or a chain's sum for this very count
         }
         if (src == 3) continue;
         if (src == 2) v = a.fscore[s];

@@ -168,6 +168,8 @@ struct utm_ctx {
     SeqChunk *d_seq_alt = nullptr;  // ... the same with the other buffer of every pair (swapped together)
     CandBuf *d_cand = nullptr;
     unsigned *d_arrivals = nullptr;  // workgroups of a k_chain launch that have finished (its last one runs the pick)
+    u64 *d_known_cnt = nullptr;      // chains' sums on record, by sample (PickArgs::known_*)
+    double *d_known_val = nullptr;
     VerifySync *d_vsync = nullptr;   // k_verify's stage words (one-launch verification on the only shard)
     unsigned verify_launches = 0;    // k_verify launches so far: the number the next one publishes (never reused)
     ChainFast chain_fast{nullptr, 0, nullptr, nullptr, 0, 0};  // device buffers of the chains' fast path
@@ -282,7 +284,7 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
 static const char *const g_env_knobs[] = {
     "UTM_TARGET_WGS", "UTM_MIN_WGS", "UTM_MIN_WGS_BIG", "UTM_TILE_STEPS", "UTM_NT_LOADS", "UTM_NT_MIN_MB", "UTM_FUSE_PICK",
     "UTM_PICK_THREADS", "UTM_BATCH", "UTM_AF_STEPS", "UTM_AF_SWITCH", "UTM_AF_TARGET_WGS", "UTM_DECR_FIRST_BATCH",
-    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER", "UTM_CHAIN_PICK", "UTM_AF_DEFER", "UTM_AF_VERIFY"};
+    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER", "UTM_CHAIN_PICK", "UTM_AF_DEFER", "UTM_AF_VERIFY", "UTM_AF_RECORD"};
 static void report_env_once()
 {
     static bool said = false;
@@ -334,6 +336,9 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     HIP_TRY(hipMalloc(&c->d_cand, sizeof(CandBuf)));
     HIP_TRY(hipMalloc(&c->d_arrivals, 128));
     HIP_TRY(hipMemsetAsync(c->d_arrivals, 0, 128, c->stream));
+    HIP_TRY(hipMalloc(&c->d_known_cnt, (size_t)n_samp_local * 8));
+    HIP_TRY(hipMalloc(&c->d_known_val, (size_t)n_samp_local * 8));
+    HIP_TRY(hipMemsetAsync(c->d_known_cnt, 0xFF, (size_t)n_samp_local * 8, c->stream));
     HIP_TRY(hipMalloc(&c->d_vsync, sizeof(VerifySync)));
     HIP_TRY(hipMemsetAsync(c->d_vsync, 0, sizeof(VerifySync), c->stream));
     HIP_TRY(hipMalloc(&c->d_cnt_keep, (size_t)n_samp_local * 8));
@@ -374,6 +379,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_arrivals);
     (void)hipFree(c->d_vsync);
+    (void)hipFree(c->d_known_cnt); (void)hipFree(c->d_known_val);
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
