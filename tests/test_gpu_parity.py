@@ -978,3 +978,29 @@ def test_af_verification_forms_agree_while_processes_share_the_gpu(dev, env):
         assert err is None and ok, (seed, err)
         assert chained > 0                                   # the data does force chains
         assert (deferred > 0) == (env.get("UTM_AF_DEFER") != "0")
+
+
+def test_af_tie_groups_are_chained_once(dev):
+    """Samples with equally many private variants of one and the same frequency tie at the top, one group after the
+    other (what the tail of a real run looks like).  A chain's float64 sum stays on record for as long as the sample's
+    count does not change, so each group costs ONE chained iteration, not one per member -- and the rows and scores
+    are the oracle's all the same."""
+    n_groups, per_group = 12, 5
+    n_samp = n_groups * per_group
+    sizes = [400 - 30 * (i // per_group) for i in range(n_samp)]          # group g: 400 - 30 g private variants each
+    n_shared = 500
+    n_var = n_shared + sum(sizes)
+    rng = np.random.default_rng(5)
+    dense = np.zeros((n_var, n_samp), bool)
+    dense[:n_shared] = rng.random((n_shared, n_samp)) < 0.5               # shared variants: gone after a few picks
+    at = n_shared
+    for i, k in enumerate(sizes):
+        dense[at:at + k, i] = True
+        at += k
+    order = rng.permutation(n_var)                                         # private blocks interleaved along the variant axis
+    dense = dense[order]
+    af = np.full(n_var, 1.0 / 5008.0)                                      # float64, not a float32 value: estimates are never exact
+    af[order < n_shared] = rng.uniform(0.01, 0.4, size=int((order < n_shared).sum()))
+    got, st = check_run(dev, dense, af=af)
+    assert len(got[0]) == n_samp
+    assert st["af_chained_iterations"] <= n_groups + 8, st               # one per group (+ the shared phase's near-ties)
