@@ -21,6 +21,7 @@
 __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c, double &lo, double &hi, double &est,
                                             bool &exact, bool &est_exact)
 {
+    const u64 on_record = a.known_cnt ? a.known_cnt[s] : ~0ull;  // (requested together with the sum, not behind it)
     const i64 e = a.afsum[s];
     est = (double)e * a.af_scale;
     const double top = a.af_trunc ? est + (double)c * a.af_scale : est;  // upper end of the exact float32 sum
@@ -33,7 +34,7 @@ __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c
         rel = 1.05 * ((double)c * 1.1102230246251565e-16 + 1.2e-16);
     }
     est_exact = exact;
-    if (!exact && a.known_cnt && a.known_cnt[s] == c) {
+    if (!exact && on_record == c) {
         est = a.known_val[s];
         exact = true;
     }
