@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Distribution of ONE kernel's duration in a rocprofv3 kernel trace (mean, deciles over the run, quantiles):
+tools/kernel_dist.py <rocprofv3 output dir> <kernel name fragment>"""
 import csv,glob,sys
 import numpy as np
 f=glob.glob(sys.argv[1]+"/runc/*kernel_trace.csv")[0]
