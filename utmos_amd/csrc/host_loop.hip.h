@@ -81,7 +81,7 @@ static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
 
 // AF, dense phase: LDS AF tiles.  Every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache), so
 // the groups hold >= 64 samples.
-static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
+static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta_fold = false)
 {
     static const int af_target = tune_env("UTM_AF_TARGET_WGS", 16384);
     const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
@@ -91,7 +91,9 @@ static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub)
     LaunchTimer t(c);
     hipExtLaunchKernelGGL(k_score_afq, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(256), 0, c->stream, t.start, t.stop, 0, ch.cols,
                           ch.covered, ch.wp, ch.afx, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,
-                          group, n_groups);
+                          group, n_groups, delta_fold ? ch.covered_alt : nullptr,
+                          (delta_fold && defer_active(c) && c->enq_iter > 0)
+                              ? c->d_newly_log + (u64)((c->enq_iter - 1) % UTM_DEFER_SLOTS) * c->col_words + ch.off : nullptr);
 }
 
 // The streaming kernels (k_score_int, k_score_afs): grid = variant tiles x groups of samples.  Tile = the largest
@@ -192,7 +194,18 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, int fuse_pic
             // the mask is made while the tiles are staged; the updated covered words land in the other buffer of each
             // chunk's pair, which becomes the current one for everything enqueued from here on (utm_run undoes the
             // swaps of launches that a finished loop skipped)
-            for (auto &ch : c->chunks) launch_score_streaming(c, ch, a_ub, /*delta=*/true, IntLaunch(), /*fold=*/true);
+            // While a winner still newly covers percents of all variants (the first iterations of a run) every surviving
+            // bit of a delta pass is a gather: those passes take the LDS-tile kernel, the rest the streaming one.  (By
+            // the last gain the host has seen: batches are 4 iterations long while this matters.  At 10M x 2,504 the
+            // first three delta passes take 1.8 / 1.3 / 1.1 ms there instead of 4.6 / 2.2 / 1.6 ms; from the fourth on
+            // the streaming kernel is ahead.)
+            const char *dd = getenv("UTM_AF_DENSE_DELTA");  // read per call: tests flip it
+            const double dense_delta = dd && *dd ? atof(dd) : 0.05;
+            const bool in_lds = c->last_new < 0 || (double)c->last_new > dense_delta * (double)c->n_var_total;
+            for (auto &ch : c->chunks) {
+                if (in_lds) launch_score_af_dense(c, ch, a_ub, /*delta_fold=*/true);
+                else launch_score_streaming(c, ch, a_ub, /*delta=*/true, IntLaunch(), /*fold=*/true);
+            }
             swap_covered(c);
             c->cov_swaps_enqueued += 1;
         }
@@ -454,7 +467,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     while (enq < k_max && !c->finished) {
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
         // ... and so is the switch to decremental iterations
-        const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, 8)
+        const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, c->iter < 8 ? 4 : 8)
                                : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, decr_first)
                                                                                             : batch;
         const i64 n = std::min<i64>(this_batch, k_max - enq);

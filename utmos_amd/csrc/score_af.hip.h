@@ -23,12 +23,16 @@ __device__ __forceinline__ u64 af_fixed(unsigned f)
 // ------------------------------------------------------------------------------------------------
 #define UTM_AF_TILE_WORDS 128
 #define UTM_DEFER_SLOTS 64  // iterations whose newly-covered masks the log holds (af_defer.hip.h)
+// covered_out != nullptr: a *delta* pass as in k_score_afs below -- the tile's mask is what the pending winner newly
+// covers, the shares are subtracted, group 0 writes covered | winner into the other buffer of the pair (and the mask
+// into the log of af_defer.hip.h).  The form for the first iterations of a run, when a winner still newly covers
+// percents of all variants: every surviving bit is a gather, and here the gathers hit LDS.
 __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                    const unsigned *__restrict__ af,
                                                    const Pending pend,
                                                    const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                    u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
-                                                   unsigned n_groups)
+                                                   unsigned n_groups, u64 *__restrict__ covered_out, u64 *__restrict__ newly_log)
 {
     __shared__ unsigned aft[UTM_AF_TILE_WORDS * 64];  // fixed-point table entries
     __shared__ u64 live[UTM_AF_TILE_WORDS];
@@ -36,14 +40,24 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
     unsigned tile, grp;
     if (!tile_of_block(wp, UTM_AF_TILE_WORDS, n_groups, tile, grp)) return;
     const u64 w0 = (u64)tile * UTM_AF_TILE_WORDS;
-    const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
+    const bool delta = covered_out != nullptr;
+    const u64 *wcol = (delta || pend.fuse) ? pending_column(st, cols, wp, pend) : nullptr;
     if (threadIdx.x < UTM_AF_TILE_WORDS) {
         u64 c = covered[w0 + threadIdx.x];
-        if (wcol) {
-            c |= wcol[w0 + threadIdx.x];
-            if (grp == 0) covered[w0 + threadIdx.x] = c;
+        if (delta) {
+            const u64 w = wcol ? wcol[w0 + threadIdx.x] : 0ull;
+            if (grp == 0) {
+                covered_out[w0 + threadIdx.x] = c | w;
+                if (newly_log && wcol) newly_log[w0 + threadIdx.x] = w & ~c;
+            }
+            live[threadIdx.x] = w & ~c;
+        } else {
+            if (wcol) {
+                c |= wcol[w0 + threadIdx.x];
+                if (grp == 0) covered[w0 + threadIdx.x] = c;
+            }
+            live[threadIdx.x] = ~c;
         }
-        live[threadIdx.x] = ~c;
     }
     {
         const v4u *src = reinterpret_cast<const v4u *>(af + w0 * 64);
@@ -89,9 +103,9 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
             }
             const unsigned n = wave_sum_u32(n_lane);
             const i64 total = wave_sum_u63(sum);  // per lane < 2^53 (the host's exactness precondition)
-            if (lane == 0) {
-                atomicAdd(&cnt[s[u]], (u64)n);
-                atomicAdd(reinterpret_cast<u64 *>(&afsum[s[u]]), (u64)total);
+            if (lane == 0) {  // two's complement: adding the negated value subtracts
+                atomicAdd(&cnt[s[u]], delta ? (u64)0 - (u64)n : (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s[u]]), delta ? (u64)0 - (u64)total : (u64)total);
             }
         }
     }

@@ -284,7 +284,7 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
 static const char *const g_env_knobs[] = {
     "UTM_TARGET_WGS", "UTM_MIN_WGS", "UTM_MIN_WGS_BIG", "UTM_TILE_STEPS", "UTM_NT_LOADS", "UTM_NT_MIN_MB", "UTM_FUSE_PICK",
     "UTM_PICK_THREADS", "UTM_BATCH", "UTM_AF_STEPS", "UTM_AF_SWITCH", "UTM_AF_TARGET_WGS", "UTM_DECR_FIRST_BATCH",
-    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER", "UTM_CHAIN_PICK", "UTM_AF_DEFER", "UTM_AF_VERIFY", "UTM_AF_RECORD"};
+    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER", "UTM_CHAIN_PICK", "UTM_AF_DEFER", "UTM_AF_VERIFY", "UTM_AF_RECORD", "UTM_AF_DENSE_DELTA"};
 static void report_env_once()
 {
     static bool said = false;
