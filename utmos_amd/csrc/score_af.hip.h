@@ -74,9 +74,8 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
     const u64 m0 = live[2 * lane], m1 = live[2 * lane + 1];
     const unsigned *a0 = aft + (2 * lane) * 64, *a1 = a0 + 64;
     constexpr int U = 4;
-    for (unsigned i0 = lo + wave * U; i0 < hi; i0 += 4 * U) {
-        unsigned s[U];
-        v2q x[U];
+    // a batch = U samples' KiB of this tile per wave; the next batch is requested before this one is walked
+    auto request = [&](unsigned i0, unsigned *s, v2q *x) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned i = i0 + u < hi ? i0 + u : hi - 1;  // tail: re-read the last sample, ignored below
@@ -85,6 +84,19 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 #pragma unroll
         for (int u = 0; u < U; ++u)
             x[u] = __builtin_nontemporal_load(reinterpret_cast<const v2q *>(cols + (u64)s[u] * wp + w0) + lane);
+    };
+    unsigned s_next[U];
+    v2q x_next[U];
+    if (lo + wave * U < hi) request(lo + wave * U, s_next, x_next);
+    for (unsigned i0 = lo + wave * U; i0 < hi; i0 += 4 * U) {
+        unsigned s[U];
+        v2q x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            s[u] = s_next[u];
+            x[u] = x_next[u];
+        }
+        if (i0 + 4 * U < hi) request(i0 + 4 * U, s_next, x_next);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             u64 b0 = x[u].x & m0, b1 = x[u].y & m1;
