@@ -603,7 +603,7 @@ def test_decremental_survives_peek_and_covered_reads(dev):
 
 def test_parity_at_production_tile_sizes(dev):
     """2M variants x 2,504 samples (the BASELINE sample count, full 32 KiB tiles, ~24k workgroups per
-    launch): first iterations of the integer and float32-AF loops against the OpenMP C oracle on the
+    launch): first iterations of the integer, float32-AF and float64-AF loops against the OpenMP C oracle on the
     matrix downloaded from the device."""
     n_var, n_samp, k = 2_000_000, 2504, 24
     with dev.DeviceMatrix(n_samp) as m:
@@ -622,6 +622,15 @@ def test_parity_at_production_tile_sizes(dev):
         got = m.run(k)
         exp = ou.c_greedy(cols, n_var, state, af=af, k_max=k, omp=True)
         assert got[0].tolist() == exp[0].tolist() and got[2].tolist() == exp[2].tolist()
+        # ... and of the float64-AF loop (the reference's in-memory values): LDS-tile delta passes first, then the
+        # streaming ones; verification in one launch; every reported score finished after its batch -- bit for bit
+        af64 = af.astype(np.float64) / 3.0
+        m.set_af(c, af64)
+        m.reset()
+        got = m.run(k)
+        exp = ou.c_greedy(cols, n_var, state, af=af64, k_max=k, omp=True)
+        assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
+        assert m.stats()["af_deferred_rows"] > 0
 
 
 def test_parity_with_many_samples(dev):
