@@ -314,6 +314,8 @@ def workload_label(spec):
 
 def headline_line(args, world, n_total, exchange, exchange_note, final_stats, st, res, head, roofline):
     """The JSON line's fields that the headline measurement alone decides (the legs behind it fill in the rest)."""
+    from utmos_amd import _native
+    env_overrides = _native.env_overrides()
     return {
         "metric": METRIC, "value": head["value"], "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
@@ -334,6 +336,9 @@ def headline_line(args, world, n_total, exchange, exchange_note, final_stats, st
         "hbm_gbps_whole_loop": head["hbm_gbps_whole_loop"], "hbm_frac_whole_loop": head["hbm_frac_whole_loop"],
         "device_loop_ms_per_step": head["device_loop_ms_per_step"],
         "sharded_rows_match_single_gpu": None,
+        # UTM_* knobs set in this process's environment (launch shapes / thresholds / test hooks, never results): a
+        # value left behind by an experiment must not go unnoticed in a recorded line
+        "env_overrides": env_overrides,
         "roofline": roofline, "cpu_baseline": None, "cpu_bitset_baseline": None, "also": None,
     }
 
@@ -444,7 +449,8 @@ def main():
                 # (straight to the process's own stdout: while a communicator is being set up, fd 1 is parked on stderr
                 # to keep RCCL's banner out of the line -- device.comm_init)
                 os.write(real_stdout, (json.dumps(early["line"]) + "\n").encode())
-            os._exit(0 if early["line"] is not None or rank != 0 else 3)
+            # measured, but the RCCL legs hung: the line is out, the exit status says so (4); no headline at all: 3
+            os._exit(4 if early["line"] is not None or rank != 0 else 3)
 
         if rank == 0:
             early["line"] = headline_line(args, world, n_total, exchange, exchange_note, m.stats(), st, res,
@@ -480,6 +486,7 @@ def main():
         m.p2p_use_mailboxes(True)             # back to the headline's exchange for the check below
         sync_max(0.0)
         watchdog.cancel()
+    os.close(real_stdout)
 
     # PMC traffic cannot be read from inside the process: two counter passes in child processes (N = 1), else the
     # passes recorded under profiles/ for the default configurations (tools/summarize_profile.py)

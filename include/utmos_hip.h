@@ -26,7 +26,10 @@
  *     fails with UTM_ESTATE on a shard that has neither.
  *
  * Environment.  None of these changes a result; they move launch shapes and thresholds (tools/tune.py sweeps them)
- * or are test hooks.  The first context of a process lists on stderr the ones that are set.
+ * or are test hooks.  ONE table in utmos_amd/csrc/utmos_hip.hip (g_knobs) names them all with their defaults; a context
+ * reads them at utm_ctx_create and again at every utm_reset (read_tune) and nowhere else, so nothing on the
+ * per-iteration path touches the environment.  The first context of a process lists on stderr the ones that are set;
+ * utm_env_overrides() returns the same list (bench.py reports it as `env_overrides`).
  *   UTM_TARGET_WGS (32768)    workgroups a scoring launch aims for          UTM_MIN_WGS (128), UTM_MIN_WGS_BIG (8192)
  *   UTM_TILE_STEPS (auto)     force the covered tile to 32/16/8/4/2 KiB     smallest grids the 8 KiB / 32 KiB tiles are used for
  *   UTM_NT_LOADS (auto)       non-temporal column loads on/off              UTM_NT_MIN_MB (512) matrix size from which they are used
@@ -59,7 +62,8 @@ extern "C" {
 #define UTM_ESTATE (-4)   /* call not valid in the context's current state */
 #define UTM_ECOMM (-5)    /* RCCL error / RCCL not available */
 
-#define UTM_ABI_VERSION 2 /* 2: utm_stats.exchange / rccl_ranks; host-memory mailbox and replica entry points removed */
+#define UTM_ABI_VERSION 3 /* 2: utm_stats.exchange / rccl_ranks; host-memory mailbox and replica entry points removed
+                           * 3: utm_env_overrides */
 
 typedef struct utm_ctx utm_ctx;
 
@@ -115,6 +119,9 @@ typedef struct utm_stats {
 const char *utm_last_error(void);
 int utm_abi_version(void);
 int utm_device_count(int *n);
+/* The UTM_* environment knobs that are set right now, as "NAME=value NAME=value" (empty string: none), into buf[cap].
+ * A context reads the knobs when it is created and again at every utm_reset -- never inside the loop. */
+int utm_env_overrides(char *buf, uint64_t cap);
 /* Free and total HBM of a device in bytes (hipMemGetInfo): what the host's is_memsafe policy (select.py:56-63) asks. */
 int utm_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 

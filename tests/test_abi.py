@@ -28,7 +28,7 @@ def test_ctypes_prototypes_cover_the_header():
 def test_abi_version_and_struct_sizes():
     import ctypes
     from utmos_amd import _native as nat
-    assert nat.lib().utm_abi_version() == 2
+    assert nat.lib().utm_abi_version() == 3
     assert ctypes.sizeof(nat.Record) == 64
     assert ctypes.sizeof(nat.Stats) == 8 * 6 + 4 * 4 + 8 * 4 + 4 * 2 + 8 * 2
 

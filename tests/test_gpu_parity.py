@@ -940,6 +940,27 @@ def test_af_scores_finished_after_their_batch_are_the_reference_sums(dev, kind):
             assert (i, n, s) == (exp[0][it], exp[1][it], exp[2][it])
 
 
+@pytest.mark.parametrize("batch", ["128", "7"])
+def test_af_deferred_scores_with_a_batch_longer_than_the_mask_log(dev, batch, monkeypatch):
+    """UTM_BATCH beyond the 64 slots of the newly-covered-mask log: the AF loop clamps its batch to the
+    log, so every deferred float64 score is still the oracle's -- and a short odd batch works too."""
+    monkeypatch.setenv("UTM_BATCH", batch)
+    rng = np.random.default_rng(5)
+    n_var, n_samp = 50_000, 400
+    dense = ou.random_dense(rng, n_var, n_samp, density=0.02)
+    af = rng.uniform(1e-4, 0.5, size=n_var)
+    cols = npo.pack_columns(dense)
+    state = np.ones(n_samp, np.uint8)
+    exp = ou.c_greedy(cols, n_var, state, None, af)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols)
+        m.set_af(c, af)
+        got = m.run(n_samp)
+        assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
+        assert m.stats()["af_deferred_rows"] > 0.5 * len(exp[0])
+
+
 def _af_run_worker(seed, env, q):
     """One whole float64-AF selection in a process of its own (spawned): (seed, rows, scores as hex)."""
     import os

@@ -47,6 +47,7 @@ _U64, _U32, _I32, _I64 = ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32, ctype
 # name -> argtypes, exactly the prototypes of include/utmos_hip.h (tests/test_abi.py checks the list)
 PROTOTYPES = {
     "utm_abi_version": [],
+    "utm_env_overrides": [ctypes.c_char_p, _U64],
     "utm_device_count": [ctypes.POINTER(ctypes.c_int)],
     "utm_device_memory": [ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
     "utm_ctx_create": [ctypes.c_int, _U32, _U32, _U32, _U32, ctypes.POINTER(_P)],
@@ -114,6 +115,13 @@ def lib():
 def check(code):
     if code != UTM_OK:
         raise NativeError(code, lib().utm_last_error().decode("utf-8", "replace"))
+
+
+def env_overrides():
+    """The UTM_* environment knobs that are set, as {name: value} (what a context would pick up at its next reset)."""
+    buf = ctypes.create_string_buffer(2048)
+    check(lib().utm_env_overrides(buf, 2048))
+    return dict(kv.split("=", 1) for kv in buf.value.decode().split())
 
 
 def device_count():

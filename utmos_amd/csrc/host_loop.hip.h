@@ -83,7 +83,7 @@ static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
 // the groups hold >= 64 samples.
 static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta_fold = false)
 {
-    static const int af_target = tune_env("UTM_AF_TARGET_WGS", 16384);
+    const int af_target = c->tune.af_target_wgs;
     const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
     unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)af_target / std::max<u64>(1, tiles)));
     const unsigned group = ((a_ub + n_groups - 1) / n_groups + 15) / 16 * 16;
@@ -102,17 +102,14 @@ static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub, bo
 static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta = false, const IntLaunch &how = IntLaunch(),
                                    bool fold = false)
 {
-    static const int target_wgs = tune_env("UTM_TARGET_WGS", 32768);
-    static const int min_wgs = tune_env("UTM_MIN_WGS", 128);  // (1024 before the pick moved into the launch: 8 KiB tiles now win down to the last iterations)
-    static const int min_wgs_big = tune_env("UTM_MIN_WGS_BIG", 8192);  // the 32 KiB tile wants a deeper grid (chr22-sized: +17 % with 8 KiB)
-    static const int force_steps = tune_env("UTM_TILE_STEPS", 0);
-    static const int nt_env = tune_env("UTM_NT_LOADS", -1);
-    static const int nt_min_mb = tune_env("UTM_NT_MIN_MB", 512);
+    const Tune &tn = c->tune;  // (defaults and what each knob is for: g_knobs, utmos_hip.hip)
+    const int target_wgs = tn.target_wgs, min_wgs = tn.min_wgs, min_wgs_big = tn.min_wgs_big, force_steps = tn.tile_steps;
+    const int nt_env = tn.nt_loads, nt_min_mb = tn.nt_min_mb;
     // non-temporal column loads when the matrix is a stream far larger than the 256 MB Infinity Cache (+10 % at
     // 3 GB); a matrix that (nearly) fits is better left to the caches (chr22-sized 345 MB: +5 %).  By the matrix, not
     // by the columns still selectable: the tail of a 3 GB select-all run measured slower with cached loads.
     const bool use_nt = nt_env >= 0 ? nt_env != 0 : (u64)c->n_local * c->col_words * 8 > ((u64)nt_min_mb << 20);
-    static const int af_big = tune_env("UTM_AF_STEPS", 16) == 32 ? 32 : 16;
+    const int af_big = tn.af_steps == 32 ? 32 : 16;
     const bool af = c->af_mode != UTM_AF_NONE;
     const u64 steps_total = ch.wp / UTM_STEP_WORDS;
     const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
@@ -175,8 +172,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, int fuse_pic
         if (!c->keep_valid) {
             HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream));
             HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
-            const char *sw = getenv("UTM_AF_SWITCH");  // read per call: tests flip it
-            const double af_switch = sw && *sw ? atof(sw) : 0.2;
+            const double af_switch = c->tune.af_switch;
             const bool af_dense = (double)c->captured_seen < af_switch * (double)c->n_var_total;
             if (remote_reads(c)) launch_apply_pending(c);
             for (auto &ch : c->chunks) {
@@ -199,8 +195,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, int fuse_pic
             // the last gain the host has seen: batches are 4 iterations long while this matters.  At 10M x 2,504 the
             // first three delta passes take 1.8 / 1.3 / 1.1 ms there instead of 4.6 / 2.2 / 1.6 ms; from the fourth on
             // the streaming kernel is ahead.)
-            const char *dd = getenv("UTM_AF_DENSE_DELTA");  // read per call: tests flip it
-            const double dense_delta = dd && *dd ? atof(dd) : 0.05;
+            const double dense_delta = c->tune.af_dense_delta;
             const bool in_lds = c->last_new < 0 || (double)c->last_new > dense_delta * (double)c->n_var_total;
             for (auto &ch : c->chunks) {
                 if (in_lds) launch_score_af_dense(c, ch, a_ub, /*delta_fold=*/true);
@@ -211,7 +206,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, int fuse_pic
         }
     } else {
         if (remote_reads(c)) launch_apply_pending(c);  // remote column: read it once, not once per workgroup
-        static const int fuse_env = tune_env("UTM_FUSE_PICK", 1);
+        const int fuse_env = c->tune.fuse_pick;
         IntLaunch how;
         how.by_pos = !by_sample;
         for (size_t k = 0; k < c->chunks.size(); ++k) {
@@ -313,7 +308,7 @@ static bool enqueue_candidates(utm_ctx *c, PickArgs a, bool pick_inside)
 {
     if (!a.cand) return false;
     a.early_pick = pick_inside ? 1 : 0;
-    static const int verify_env = tune_env("UTM_AF_VERIFY", 1);
+    const int verify_env = c->tune.af_verify;
     if (pick_inside && verify_env) {
         // the only shard: candidates, their addends, their chains and the pick as stages of ONE launch (k_verify)
         const ChainFast &cf = c->chain_fast;
@@ -337,12 +332,12 @@ static bool enqueue_candidates(utm_ctx *c, PickArgs a, bool pick_inside)
 
 static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
 {
-    static const int pick_env = tune_env("UTM_PICK_THREADS", 0);
+    const int pick_env = c->tune.pick_threads;
     // single shard: 512 threads scan a few thousand counts as fast as 1024 and launch / join quicker (1024, 512, 256,
     // 128, 64 threads: 626.8, 623.6, 625.1, 629.6, 641.3 ms per cfg2 run)
     const unsigned pick_threads = pick_env ? (unsigned)pick_env : c->active_ub > 16384 ? 1024 : 512;
     PickArgs a = pick_args(c, decr);
-    static const int chain_pick = tune_env("UTM_CHAIN_PICK", 1);
+    const int chain_pick = c->tune.chain_pick;
     const bool only_shard = c->n_ranks == 1 && c->n_local == c->n_total && !c->comm;
     if (enqueue_candidates(c, a, /*pick_inside=*/only_shard && chain_pick)) {
         HIP_TRY(hipGetLastError());
@@ -458,10 +453,13 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     HIP_TRY(hipEventRecord(c->ev_loop0, c->stream));
     // iterations enqueued between two host syncs: AF modes latch host-side decisions there (64); the integer loop
     // only needs the stop flag (256: a boundary costs an idle device for two round trips)
-    static const int batch_env = tune_env("UTM_BATCH", 0);
-    static const int decr_first = std::max(1, tune_env("UTM_DECR_FIRST_BATCH", 8));
+    const int batch_env = c->tune.batch;
+    const int decr_first = std::max(1, c->tune.decr_first_batch);
     // (RCCL exchange: one iteration per sync -- the column broadcast's root is only known on the host after it)
-    const int batch = rccl_needs_root(c) ? 1 : batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
+    int batch = rccl_needs_root(c) ? 1 : batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
+    // deferred exact AF scores log one newly-covered mask per row of a batch in UTM_DEFER_SLOTS slots (row % slots):
+    // a longer batch would overwrite masks that are not finished yet
+    if (c->af_mode != UTM_AF_NONE && c->af_fixed && defer_active(c)) batch = std::min(batch, (int)UTM_DEFER_SLOTS);
     i64 enq = 0;
     bool tail_deferred = false;  // the last batch left its last row's exact score to the end of the run
     while (enq < k_max && !c->finished) {

@@ -222,7 +222,7 @@ static int build_af_tables(utm_ctx *c)
         // chained on the spot, as before
         (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
         c->d_newly_log = nullptr; c->d_defer_counts = nullptr; c->d_defer_offs = nullptr; c->d_defer_vals = nullptr;
-        static const int defer_env = tune_env("UTM_AF_DEFER", 1);
+        const int defer_env = c->tune.af_defer;
         u64 slots = 0;  // addend slots: every word that holds variants
         for (auto &ch : c->chunks) slots += ch.w * 64;
         const size_t need = (size_t)UTM_DEFER_SLOTS * c->col_words * 8 + slots * 8 + (size_t)UTM_DEFER_SLOTS * n * 12 + 8;

@@ -34,8 +34,7 @@ static u64 interleaved_stride(const utm_ctx *c) { return round_up((u64)c->n_loca
 
 static int ensure_interleaved(utm_ctx *c)
 {
-    const char *env = getenv("UTM_DECR_INTERLEAVED");  // read per reset: tests flip it
-    const bool wanted = !(env && *env == '0');
+    const bool wanted = c->tune.decr_interleaved != 0;
     const u64 s_t = interleaved_stride(c);
     bool have_all = true;
     u64 need = 0;
@@ -105,6 +104,8 @@ extern "C" int utm_reset(utm_ctx *c)
 {
     CTX(c);
     if (c->chunks.empty()) return fail(UTM_ESTATE, "no chunks");
+    read_tune(&c->tune);  // the one place a live context picks up changed environment knobs
+    c->remote_winner_test = c->tune.test_remote_winner == 1;
     TRY(build_af_tables(c));
     TRY(ensure_xbuf(c, std::max(c->xbuf_ranks, c->n_ranks)));
     // local state + active list
@@ -246,7 +247,7 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     // come later, from the deferred launches
     a.af_skip_single = ((!c->af_exact_scores || defer_active(c)) && c->n_local == c->n_total) ? 1 : 0;
     a.early_pick = 0;  // (enqueue_candidates decides)
-    static const int record_env = tune_env("UTM_AF_RECORD", 1);
+    const int record_env = c->tune.af_record;
     a.known_cnt = (a.cand && record_env) ? c->d_known_cnt : nullptr;
     a.known_val = c->d_known_val;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);

@@ -209,8 +209,7 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
         for (int r = 0; r < n_ranks; ++r)
             if (r != rank) need += (u64)locals[r] * c->col_words * 8;
         size_t free_b = 0, total_b = 0;
-        const char *env = getenv("UTM_P2P_REPLICATE");
-        const bool wanted = n_ranks > 1 && !(env && *env == '0');
+        const bool wanted = n_ranks > 1 && c->tune.p2p_replicate != 0;
         if (wanted && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (u64)free_b > need + (8ull << 30)) {
             // allocate everything first: a refusal (another process took the room meanwhile) just keeps the in-place reads
             bool room = true;

@@ -112,6 +112,85 @@ static int rccl_load()
             return fail(UTM_ECOMM, "%s -> %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
+
+// ---------------------------------------------------------------------------------------- environment knobs
+// Every environment variable the library reads, in ONE table (include/utmos_hip.h "Environment" documents them).  They
+// only move launch shapes, thresholds and test hooks -- never results.  A context reads them when it is created and
+// again at every utm_reset (read_tune): nothing on the per-iteration path calls getenv, and a test that flips a knob
+// takes effect at its next reset.  The first context of a process names the ones that are set, once, on stderr;
+// utm_env_overrides() returns the same list (bench.py puts it into its JSON line).
+struct Tune {
+    int target_wgs, min_wgs, min_wgs_big, tile_steps, nt_loads, nt_min_mb;  // scoring grid shape
+    int fuse_pick, pick_threads, batch;                                      // pick placement, host sync distance
+    int af_steps, af_target_wgs, chain_pick, af_verify, af_record, af_defer; // AF kernels
+    double af_switch, af_dense_delta;
+    int decr_first_batch, decr_interleaved;                                  // decremental mode
+    int p2p_replicate, test_remote_winner;                                   // shards
+    int persistent, persist_max_mb, persist_wgs_per_cu, test_drop_arrival;   // persistent loop kernel
+};
+struct KnobDef {
+    const char *name;
+    int is_double;
+    size_t offset;
+    double dflt;
+};
+#define UTM_KNOB_I(env, field, dflt) {env, 0, offsetof(Tune, field), (double)(dflt)}
+#define UTM_KNOB_D(env, field, dflt) {env, 1, offsetof(Tune, field), (double)(dflt)}
+static const KnobDef g_knobs[] = {
+    UTM_KNOB_I("UTM_TARGET_WGS", target_wgs, 32768),
+    UTM_KNOB_I("UTM_MIN_WGS", min_wgs, 128),          // (1024 before the pick moved into the launch: 8 KiB tiles now win down to the last iterations)
+    UTM_KNOB_I("UTM_MIN_WGS_BIG", min_wgs_big, 8192), // the 32 KiB tile wants a deeper grid (chr22-sized: +17 % with 8 KiB)
+    UTM_KNOB_I("UTM_TILE_STEPS", tile_steps, 0),
+    UTM_KNOB_I("UTM_NT_LOADS", nt_loads, -1),
+    UTM_KNOB_I("UTM_NT_MIN_MB", nt_min_mb, 512),
+    UTM_KNOB_I("UTM_FUSE_PICK", fuse_pick, 1),
+    UTM_KNOB_I("UTM_PICK_THREADS", pick_threads, 0),
+    UTM_KNOB_I("UTM_BATCH", batch, 0),
+    UTM_KNOB_I("UTM_AF_STEPS", af_steps, 16),
+    UTM_KNOB_I("UTM_AF_TARGET_WGS", af_target_wgs, 16384),
+    UTM_KNOB_I("UTM_CHAIN_PICK", chain_pick, 1),
+    UTM_KNOB_I("UTM_AF_VERIFY", af_verify, 1),
+    UTM_KNOB_I("UTM_AF_RECORD", af_record, 1),
+    UTM_KNOB_I("UTM_AF_DEFER", af_defer, 1),
+    UTM_KNOB_D("UTM_AF_SWITCH", af_switch, 0.2),
+    UTM_KNOB_D("UTM_AF_DENSE_DELTA", af_dense_delta, 0.05),
+    UTM_KNOB_I("UTM_DECR_FIRST_BATCH", decr_first_batch, 8),
+    UTM_KNOB_I("UTM_DECR_INTERLEAVED", decr_interleaved, 1),
+    UTM_KNOB_I("UTM_P2P_REPLICATE", p2p_replicate, 1),
+    UTM_KNOB_I("UTM_TEST_REMOTE_WINNER", test_remote_winner, 0),
+    UTM_KNOB_I("UTM_PERSISTENT", persistent, 1),
+    UTM_KNOB_I("UTM_PERSIST_MAX_MB", persist_max_mb, 0),
+    UTM_KNOB_I("UTM_PERSIST_WGS_PER_CU", persist_wgs_per_cu, 0),
+    UTM_KNOB_I("UTM_TEST_DROP_ARRIVAL", test_drop_arrival, 0),
+};
+static void read_tune(Tune *t)
+{
+    for (const KnobDef &k : g_knobs) {
+        const char *v = getenv(k.name);
+        const bool set = v && *v;
+        char *at = reinterpret_cast<char *>(t) + k.offset;
+        if (k.is_double) *reinterpret_cast<double *>(at) = set ? atof(v) : k.dflt;
+        else *reinterpret_cast<int *>(at) = set ? atoi(v) : (int)k.dflt;
+    }
+}
+// " NAME=value" for every knob that is set in the environment; returns the number of characters written.
+static size_t format_env_overrides(char *buf, size_t cap)
+{
+    size_t used = 0;
+    if (cap) buf[0] = 0;
+    for (const KnobDef &k : g_knobs) {
+        const char *v = getenv(k.name);
+        if (v && *v && used + 64 < cap) used += (size_t)snprintf(buf + used, cap - used, "%s%s=%.24s", used ? " " : "", k.name, v);
+    }
+    return used;
+}
+extern "C" int utm_env_overrides(char *buf, uint64_t cap)
+{
+    if (!buf || cap < 2) return fail(UTM_EINVAL, "buffer too small");
+    format_env_overrides(buf, (size_t)cap);
+    return UTM_OK;
+}
+
 // ---------------------------------------------------------------------------------------- context
 struct Chunk {
     u64 n_var = 0;
@@ -142,6 +221,7 @@ struct utm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t flags = 0;
+    Tune tune;  // environment knobs as of the last utm_reset (read_tune)
     uint32_t n_total = 0, first = 0, n_local = 0;
     std::vector<Chunk> chunks;
     u64 n_var_total = 0;
@@ -278,25 +358,13 @@ static Pending pending_of(const utm_ctx *c, const Chunk &ch, bool scoring_kernel
     return p;
 }
 
-// Every environment variable the library reads (include/utmos_hip.h "Environment" documents them).  They only move
-// launch shapes, thresholds and test hooks -- never results -- but a value left behind by an experiment should not go
-// unnoticed: the first context of a process names the ones that are set, once, on stderr.
-static const char *const g_env_knobs[] = {
-    "UTM_TARGET_WGS", "UTM_MIN_WGS", "UTM_MIN_WGS_BIG", "UTM_TILE_STEPS", "UTM_NT_LOADS", "UTM_NT_MIN_MB", "UTM_FUSE_PICK",
-    "UTM_PICK_THREADS", "UTM_BATCH", "UTM_AF_STEPS", "UTM_AF_SWITCH", "UTM_AF_TARGET_WGS", "UTM_DECR_FIRST_BATCH",
-    "UTM_DECR_INTERLEAVED", "UTM_P2P_REPLICATE", "UTM_TEST_REMOTE_WINNER", "UTM_CHAIN_PICK", "UTM_AF_DEFER", "UTM_AF_VERIFY", "UTM_AF_RECORD", "UTM_AF_DENSE_DELTA"};
 static void report_env_once()
 {
     static bool said = false;
     if (said) return;
     said = true;
     char line[1024];
-    size_t used = 0;
-    for (const char *name : g_env_knobs) {
-        const char *v = getenv(name);
-        if (v && *v && used < sizeof line - 64) used += (size_t)snprintf(line + used, sizeof line - used, " %s=%.24s", name, v);
-    }
-    if (used) fprintf(stderr, "libutmos_hip: environment overrides in effect:%s\n", line);
+    if (format_env_overrides(line, sizeof line)) fprintf(stderr, "libutmos_hip: environment overrides in effect: %s\n", line);
 }
 
 extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_sample, uint32_t n_samp_local,
@@ -313,6 +381,7 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     utm_ctx *c = new utm_ctx();
     c->device = device;
     c->flags = flags;
+    read_tune(&c->tune);
     c->n_total = n_samp_total;
     c->first = first_sample;
     c->n_local = n_samp_local;
@@ -344,10 +413,7 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     HIP_TRY(hipMalloc(&c->d_cnt_keep, (size_t)n_samp_local * 8));
     HIP_TRY(hipMalloc(&c->d_afsum_keep, (size_t)n_samp_local * 8));
     c->decr_enabled = flags & UTM_FLAG_DECREMENTAL;
-    {
-        const char *t = getenv("UTM_TEST_REMOTE_WINNER");
-        c->remote_winner_test = t && *t == '1';
-    }
+    c->remote_winner_test = c->tune.test_remote_winner == 1;
     c->xbuf_ranks = 1;
     HIP_TRY(hipEventCreate(&c->ev_loop0));
     HIP_TRY(hipEventCreate(&c->ev_loop1));
@@ -424,12 +490,6 @@ static int chunk_of(utm_ctx *c, int32_t chunk, Chunk **out)
     if (chunk < 0 || (size_t)chunk >= c->chunks.size()) return fail(UTM_EINVAL, "chunk %d not in [0,%zu)", chunk, c->chunks.size());
     *out = &c->chunks[chunk];
     return UTM_OK;
-}
-
-static int tune_env(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
 }
 
 #include "host_matrix.hip.h"

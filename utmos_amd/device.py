@@ -74,10 +74,15 @@ class DeviceMatrix:
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         nat.check(nat.lib().utm_upload_rows_packed(self._h, chunk, int(first_var), rows.shape[0], _ptr(rows), rows.shape[1]))
 
-    def download_columns(self, chunk, first_col=0, n_cols=None):
+    def download_columns(self, chunk, first_col=0, n_cols=None, out=None):
+        """Columns [first_col, first_col + n_cols) of a chunk as uint64 (n_cols, ceil(n_var/64)); `out` = a C-contiguous
+        array (or slice of whole rows of one) to fill instead of a new one -- large matrices come down in slices."""
         n_cols = self.n_local - first_col if n_cols is None else n_cols
         words = (self.chunk_vars[chunk] + 63) // 64
-        out = np.zeros((n_cols, words), dtype=np.uint64)
+        if out is None:
+            out = np.empty((n_cols, words), dtype=np.uint64)
+        elif out.dtype != np.uint64 or out.shape != (n_cols, words) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint64 array of shape (n_cols, words)")
         nat.check(nat.lib().utm_download_columns(self._h, chunk, first_col, n_cols, _ptr(out), words))
         return out
 
