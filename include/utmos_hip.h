@@ -45,6 +45,11 @@
  *   UTM_DECR_FIRST_BATCH (8), UTM_DECR_INTERLEAVED (1)                      decremental mode: first batch size, second copy on/off
  *   UTM_P2P_REPLICATE (1)     copy the peers' columns once (0: read winners in place over the mappings)
  *   UTM_TEST_REMOTE_WINNER (0) test hook: read local winners from the exchange's winner-column buffer too
+ *   UTM_PERSISTENT (1)        integer scores, one chunk, the only shard: a batch of iterations as ONE persistent launch
+ *                             (workers keep their covered tile in LDS, the picker's record replaces the kernel boundary)
+ *   UTM_PERSIST_MAX_MB (0 = no limit) largest matrix run that way; UTM_PERSIST_WGS_PER_CU (0 = what the occupancy query allows)
+ *   UTM_TEST_DROP_ARRIVAL (0) test hook: in that scoring launch / persistent iteration since the reset one partial count is
+ *                             withheld, so that the pick's bounded wait runs out (UTM_EHIP; the context works again after utm_reset)
  */
 #ifndef UTMOS_HIP_H
 #define UTMOS_HIP_H
@@ -63,7 +68,7 @@ extern "C" {
 #define UTM_ECOMM (-5)    /* RCCL error / RCCL not available */
 
 #define UTM_ABI_VERSION 3 /* 2: utm_stats.exchange / rccl_ranks; host-memory mailbox and replica entry points removed
-                           * 3: utm_env_overrides */
+                           * 3: utm_env_overrides; utm_stats.persist_launches / persist_iterations */
 
 typedef struct utm_ctx utm_ctx;
 
@@ -107,6 +112,9 @@ typedef struct utm_stats {
     /* allele-frequency scoring, verified-parallel form, since the last utm_reset: */
     int64_t af_chained_iterations; /* iterations whose pick needed sequential float64 chains on the spot (near-ties) */
     int64_t af_deferred_rows;      /* rows whose exact float64 score was finished after their batch (one launch set per batch) */
+    /* persistent loop (unweighted integer scores, one chunk, the only shard): batches of iterations run as ONE launch */
+    int64_t persist_launches;      /* such launches since the last utm_reset (each counts once in score_launches) */
+    int64_t persist_iterations;    /* rows they produced (0: every iteration was a launch of its own) */
 } utm_stats;
 
 /* utm_stats.exchange */

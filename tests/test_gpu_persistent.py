@@ -1,0 +1,127 @@
+"""The persistent loop kernel (k_loop_int, utmos_amd/csrc/loop_int.hip.h): batches of unweighted integer iterations as ONE
+launch.  Same rows as the oracle (and therefore as one launch per iteration) over ragged shapes, used / excluded samples,
+ties, zero-score stops, early full coverage, runs cut into calls, both tile sizes -- and the bounded waits' failure paths."""
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from oracle_util import npo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from utmos_amd import _native as nat
+    assert nat.device_count() >= 1, "no GPU visible"
+    from utmos_amd import device
+    return device
+
+
+def run_both(dev, dense, state=None, k=None, pieces=None, monkeypatch=None):
+    n_var, n_samp = dense.shape
+    state = np.ones(n_samp, np.uint8) if state is None else state
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, state, k_max=k)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols)
+        m.set_state(state)
+        idx, new = [], []
+        for piece in (pieces or [n_samp if k is None else k]):
+            got = m.run(piece)
+            idx += got[0].tolist()
+            new += got[1].tolist()
+            assert (got[2] == got[1]).all()
+        st = m.stats()
+        covered = m.covered(c)
+    assert idx == exp[0][:len(idx)].tolist() and new == exp[1][:len(new)].tolist()
+    if pieces is None:
+        assert len(idx) == len(exp[0])
+    # the covered mask that came back from the workers' LDS tiles = OR of the winners' columns (and of the used samples')
+    want = np.zeros(cols.shape[1], np.uint64)
+    for s in list(np.flatnonzero(state == 0)) + idx:
+        want |= cols[s]
+    assert (covered == want).all()
+    return st
+
+
+@pytest.mark.parametrize("n_var,n_samp", [(1, 1), (63, 3), (64, 4), (65, 5), (1000, 130), (8192, 64), (8193, 257), (70_000, 700),
+                                          (200_000, 37), (3_000, 3_000)])
+def test_persistent_loop_select_all(dev, n_var, n_samp):
+    rng = np.random.default_rng(n_var * 31 + n_samp)
+    st = run_both(dev, ou.random_dense(rng, n_var, n_samp))
+    assert st["persist_iterations"] == st["iterations"] > 0 and st["persist_launches"] >= 1
+
+
+def test_persistent_loop_is_what_runs_and_can_be_switched_off(dev, monkeypatch):
+    rng = np.random.default_rng(3)
+    dense = ou.random_dense(rng, 50_000, 300)
+    on = run_both(dev, dense)
+    assert on["persist_iterations"] == 300 and on["persist_launches"] == 2 and on["score_launches"] == 2      # 256 + 44
+    monkeypatch.setenv("UTM_PERSISTENT", "0")
+    off = run_both(dev, dense)
+    assert off["persist_iterations"] == 0 and off["score_launches"] >= 300
+
+
+def test_persistent_loop_states_ties_and_stops(dev):
+    rng = np.random.default_rng(11)
+    n_var, n_samp = 40_000, 500
+    dense = ou.random_dense(rng, n_var, n_samp, density=0.02)
+    dense[:, 7] = dense[:, 3]                          # exact ties: lowest index first (np.argmax)
+    dense[:, 400] = dense[:, 3]
+    state = np.ones(n_samp, np.uint8)
+    state[rng.choice(n_samp, 60, replace=False)] = 2   # excluded: never selected, never cover
+    state[[5, 99, 250]] = 0                            # start out used: cover from the first iteration
+    state[3] = 1
+    run_both(dev, dense, state)
+    run_both(dev, dense, state, k=17)
+    # cut into calls: 1, 2, 255, 256, 3 ... every call continues where the last one stopped (pending winner folded in)
+    run_both(dev, dense, state, pieces=[1, 2, 255, 256, 3, 1000])
+    # zero-score stop: half the samples carry nothing that is not covered by sample 0
+    dense2 = np.zeros((5000, 64), bool)
+    dense2[:, 0] = True
+    dense2[rng.integers(0, 5000, 300), rng.integers(1, 32, 300)] = True
+    st = run_both(dev, dense2)
+    assert st["iterations"] == 1                       # sample 0 captures everything: "ran out of new variants"
+    state2 = np.ones(64, np.uint8)
+    state2[0] = 2                                      # now the rest is selected until the best score is 0
+    st = run_both(dev, dense2, state2)
+    assert 1 <= st["iterations"] < 32
+
+
+@pytest.mark.parametrize("wgs_per_cu", ["1", "3"])
+def test_persistent_loop_with_few_resident_blocks_and_the_larger_tile(dev, wgs_per_cu, monkeypatch):
+    """UTM_PERSIST_WGS_PER_CU shrinks the grid: more variants than 8 KiB tiles x blocks -> the 16 KiB tile; and past that
+    the loop falls back to one launch per iteration (same rows)."""
+    monkeypatch.setenv("UTM_PERSIST_WGS_PER_CU", wgs_per_cu)
+    rng = np.random.default_rng(int(wgs_per_cu))
+    for n_var in (300_000, 9_000_000 if wgs_per_cu == "1" else 1_200_000):
+        n_samp = 40
+        dense = rng.random((n_var, n_samp)) < 0.05
+        dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+        run_both(dev, dense, k=12)
+
+
+def test_withheld_partial_count_ends_in_an_error_and_the_context_recovers(dev, monkeypatch):
+    """the pick's bounded wait.  UTM_TEST_DROP_ARRIVAL=n withholds one partial count in the n-th iteration
+    of a persistent launch (or the n-th scoring launch): the picker gives up after its spin budget, the loop ends with
+    UTM_EHIP, and after utm_reset the same context produces the oracle's rows."""
+    rng = np.random.default_rng(8)
+    n_var, n_samp = 30_000, 120
+    dense = ou.random_dense(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8))
+    for persistent in ("1", "0"):
+        monkeypatch.setenv("UTM_PERSISTENT", persistent)
+        monkeypatch.setenv("UTM_TEST_DROP_ARRIVAL", "5")
+        with dev.DeviceMatrix(n_samp) as m:
+            c = m.add_chunk(n_var)
+            m.upload_columns(c, cols)
+            with pytest.raises(dev.nat.NativeError) as e:
+                m.run(n_samp)
+            assert e.value.code == -2 and "did not all arrive" in str(e.value)
+            monkeypatch.setenv("UTM_TEST_DROP_ARRIVAL", "0")
+            m.reset()                                   # (re-reads the knobs)
+            got = m.run(n_samp)
+            assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()

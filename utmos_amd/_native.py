@@ -35,7 +35,8 @@ class Stats(ctypes.Structure):
                 ("decr_iterations", ctypes.c_int64), ("brute_force_bytes", ctypes.c_int64),
                 ("p2p_replica_bytes", ctypes.c_int64), ("decr_interleaved_bytes", ctypes.c_int64),
                 ("exchange", ctypes.c_int32), ("rccl_ranks", ctypes.c_int32),
-                ("af_chained_iterations", ctypes.c_int64), ("af_deferred_rows", ctypes.c_int64)]
+                ("af_chained_iterations", ctypes.c_int64), ("af_deferred_rows", ctypes.c_int64),
+                ("persist_launches", ctypes.c_int64), ("persist_iterations", ctypes.c_int64)]
 
 
 EXCHANGE_NAMES = {0: "none", 1: "mailboxes", 2: "rccl", 3: "caller-driven", 4: "rccl-allreduce"}

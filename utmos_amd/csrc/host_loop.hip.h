@@ -145,6 +145,78 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
     else launch_score_int<2>(c, t, ch, blocks, (unsigned)group, n_groups, use_nt, how);
 }
 
+// ---------------------------------------------------------------------------------------- the persistent loop
+// Shape of a k_loop_int launch for this context, or ok = false when the loop has to run as one launch per iteration:
+// unweighted integer scores, the only shard, one chunk, no decremental mode, and a tile grid that fits the blocks that
+// can be resident together.  Tile: 8 KiB while every tile then gets at least two worker slots, else 16 KiB.
+struct LoopShape {
+    bool ok = false;
+    int steps = 8;
+    unsigned q_slots = 0, n_units = 0, per_xcd = 0;
+};
+static LoopShape loop_shape(utm_ctx *c)
+{
+    LoopShape sh;
+    const Tune &tn = c->tune;
+    if (!tn.persistent || c->persist_off || c->af_mode != UTM_AF_NONE || c->have_weights || c->decr_enabled || c->chunks.size() != 1 ||
+        c->n_ranks != 1 || c->n_local != c->n_total || c->comm || c->p2p || c->n_local >= UTM_LOOP_MAX_LOCAL)
+        return sh;
+    const Chunk &ch = c->chunks[0];
+    if (tn.persist_max_mb > 0 && (u64)c->n_local * ch.wp * 8 > ((u64)tn.persist_max_mb << 20)) return sh;
+    static int cus = 0, occ8 = 0, occ16 = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return sh;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, k_loop_int<8, true>, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, k_loop_int<16, true>, 256, 0);
+        cus = prop.multiProcessorCount;
+    }
+    const u64 steps_total = ch.wp / UTM_STEP_WORDS;
+    for (int steps : {8, 16}) {
+        int per_cu = std::min(steps == 8 ? occ8 : occ16, 8);
+        if (tn.persist_wgs_per_cu > 0) per_cu = std::min(per_cu, tn.persist_wgs_per_cu);
+        const u64 max_workers = (u64)cus * (u64)std::max(per_cu, 0);
+        if (max_workers < 16) continue;
+        const u64 tiles = (steps_total + steps - 1) / steps;
+        const u64 q = (max_workers - 8) / tiles;  // (the picker's block and the padding to whole XCD rounds come out of the same budget)
+        if (q < (steps == 8 ? 2u : 1u)) continue;
+        sh.ok = true;
+        sh.steps = steps;
+        sh.q_slots = (unsigned)std::min<u64>(q, ((u64)c->n_local + 3) / 4);  // (more wave slots than samples would only idle)
+        sh.q_slots = std::max(1u, sh.q_slots);
+        sh.n_units = (unsigned)(tiles * sh.q_slots);
+        sh.per_xcd = (sh.n_units + 7) / 8;
+        return sh;
+    }
+    return sh;
+}
+
+// Up to k_batch iterations as ONE launch (k_loop_int): the picker's record replaces the kernel boundary.
+static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch)
+{
+    const Chunk &ch = c->chunks[0];
+    const bool use_nt = c->tune.nt_loads >= 0 ? c->tune.nt_loads != 0 : (u64)c->n_local * c->col_words * 8 > ((u64)c->tune.nt_min_mb << 20);
+    HIP_TRY(hipMemsetAsync(c->d_loop_sync, 0, sizeof(LoopSync), c->stream));
+    const PickArgs pa = pick_args(c);
+    const dim3 grid(8 * sh.per_xcd + 1);
+    const int drop = c->tune.test_drop_arrival;
+    LaunchTimer t(c);
+#define UTM_LAUNCH_LOOP(S, NT)                                                                                                      \
+    UTM_TIMED_LAUNCH(t, (k_loop_int<S, NT>), grid, dim3(256), (const u64 *)ch.cols, ch.covered, ch.wp, pending_of(c, ch, true), c->d_st, \
+                     c->d_act, c->d_cnt, c->d_cnt_alt, sh.q_slots, sh.n_units, sh.per_xcd, k_batch, c->d_loop_sync, pa, drop)
+    if (sh.steps == 8) {
+        if (use_nt) UTM_LAUNCH_LOOP(8, true);
+        else UTM_LAUNCH_LOOP(8, false);
+    } else {
+        if (use_nt) UTM_LAUNCH_LOOP(16, true);
+        else UTM_LAUNCH_LOOP(16, false);
+    }
+#undef UTM_LAUNCH_LOOP
+    HIP_TRY(hipGetLastError());
+    c->persist_launches += 1;
+    return UTM_OK;
+}
+
 // Every chunk's (covered, covered_alt) pair and the chain kernels' chunk tables change roles together.
 static void swap_covered(utm_ctx *c)
 {
@@ -381,6 +453,7 @@ static int sync_state(utm_ctx *c)
     c->iter = c->h_st->iter;
     c->captured_seen = c->h_st->tot;
     c->xseq_host = c->h_st->xseq;
+    if (c->h_st->xerror == 3) { c->finished = false; return UTM_OK; }  // a persistent launch's census failed: utm_run falls back
     if (c->h_st->xerror == 2) return fail(UTM_EHIP, "a scoring launch's partial counts did not all arrive at its pick (internal error)");
     if (c->h_st->xerror) return fail(UTM_ECOMM, "a shard's record did not arrive through the mailboxes in time");
     if (c->h_st->all_exact) c->af_all_exact = true;
@@ -460,6 +533,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     // deferred exact AF scores log one newly-covered mask per row of a batch in UTM_DEFER_SLOTS slots (row % slots):
     // a longer batch would overwrite masks that are not finished yet
     if (c->af_mode != UTM_AF_NONE && c->af_fixed && defer_active(c)) batch = std::min(batch, (int)UTM_DEFER_SLOTS);
+    if (c->af_mode == UTM_AF_NONE) batch = std::min(batch, 256);  // (the persistent loop's record carries an 8-bit iteration tag)
     i64 enq = 0;
     bool tail_deferred = false;  // the last batch left its last row's exact score to the end of the run
     while (enq < k_max && !c->finished) {
@@ -486,7 +560,10 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         const i64 swaps0 = c->cov_swaps_enqueued;
         // where the pick runs: inside the scoring launch on the only shard (1) and on a shard of the mailbox exchange (2)
         const int fuse_mode = (c->n_ranks > 1 && c->mbox_ok) ? 2 : (c->n_ranks == 1 && c->n_local == c->n_total && !c->comm) ? 1 : 0;
-        for (i64 j = 0; j < n; ++j) {
+        // short scans (and any matrix whose tile grid fits the resident blocks): the whole batch as ONE persistent launch
+        const LoopShape loop = (!decr && fuse_mode == 1 && c->tune.fuse_pick) ? loop_shape(c) : LoopShape();
+        if (loop.ok) TRY(enqueue_loop(c, loop, (int)n));
+        for (i64 j = 0; j < n && !loop.ok; ++j) {
             bool picked = false;
             c->enq_iter = c->iter + j;  // (exact unless the loop ends first -- and then these launches do nothing)
             if (decr) TRY(enqueue_score_decr(c));
@@ -498,6 +575,17 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         if (af_par) hipLaunchKernelGGL(k_count_sum, dim3(1), dim3(1024), 0, c->stream, c->d_st, c->d_act, c->d_cnt, 0);
         const i64 before = c->iter;
         TRY(sync_state(c));
+        if (loop.ok && c->h_st->xerror == 3) {
+            // the census failed (not every block of the grid became resident, e.g. another process holds part of the GPU):
+            // nothing was touched -- clear the mark, take the launch-per-iteration path from here on
+            c->persist_off = true;
+            c->persist_launches -= 1;
+            c->h_st->xerror = 0;
+            HIP_TRY(copy_sync(c, &c->d_st->xerror, &c->h_st->xerror, sizeof(int), hipMemcpyHostToDevice));
+            if (c->flags & UTM_FLAG_PROFILE_EVENTS) c->ev_used = 0;
+            continue;
+        }
+        if (loop.ok) c->persist_iterations += c->iter - before;
         enq += n;
         if (rccl_needs_root(c) && c->iter > before && !c->finished) {
             // second half of the RCCL exchange: the winner's column from its owner into every shard's winner-column
@@ -664,6 +752,8 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
                                                          : UTM_EXCHANGE_CALLER;
     out->af_chained_iterations = c->prepared ? (i64)c->h_st->chain_events : 0;
     out->af_deferred_rows = c->deferred_rows;
+    out->persist_launches = c->persist_launches;
+    out->persist_iterations = c->persist_iterations;
     out->rccl_ranks = 0;
     if (c->comm) {
         int n = 0;

@@ -117,6 +117,7 @@ extern "C" int utm_reset(utm_ctx *c)
     HIP_TRY(hipMemcpyAsync(c->d_state, c->h_state.data() + c->first, c->n_local, hipMemcpyHostToDevice, c->stream));
     if (!act.empty()) HIP_TRY(hipMemcpyAsync(c->d_act, act.data(), act.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_cnt_alt, 0, (size_t)c->n_local * 8, c->stream));  // (a launch that ended on an error may have left partial counts)
     HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_fscore, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_arrivals, 0, 128, c->stream));
@@ -192,6 +193,7 @@ extern "C" int utm_reset(utm_ctx *c)
     c->active_ub = (unsigned)act.size();
     c->finished = false;
     c->score_launches = 0;
+    c->persist_launches = c->persist_iterations = 0;
     c->score_ms = 0;
     c->algo_bytes = 0;
     c->ev_used = 0;
@@ -252,6 +254,7 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     a.known_val = c->d_known_val;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
     a.remote_winner_test = c->remote_winner_test ? 1 : 0;
+    a.test_drop = (c->tune.test_drop_arrival > 0 && c->score_launches == c->tune.test_drop_arrival) ? 1 : 0;  // (the launch being enqueued)
     a.res_idx = c->d_res_idx;
     a.res_new = c->d_res_new;
     a.res_score = c->d_res_score;

@@ -4,6 +4,7 @@
 #include "common.hip.h"
 #include "pick.hip.h"
 #include "score_int.hip.h"
+#include "loop_int.hip.h"
 #include "score_af.hip.h"
 #include "covered.hip.h"
 #include "decremental.hip.h"

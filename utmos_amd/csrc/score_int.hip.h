@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256, UTM_SCORE_WAVES(STEPS)) void k_score_int(const
         // counts are kept by position in act[] (by_pos) where the pick reads them by position too: one
         // dependent load less on its critical path.  FUSED: every partial arrives, a zero one too.
         if (FUSED) {
-            if (lane == 0) atomicAdd(&cnt[done_i], (u64)acc + (1ull << UTM_ARRIVAL_SHIFT));
+            const bool drop = pa.test_drop && blockIdx.x == 0 && done_i == lo;  // (test hook: see PickArgs::test_drop)
+            if (lane == 0 && !drop) atomicAdd(&cnt[done_i], (u64)acc + (1ull << UTM_ARRIVAL_SHIFT));
         } else if (lane == 0 && acc) {
             atomicAdd(&cnt[by_pos ? done_i : done_s], (u64)acc);
         }

@@ -230,6 +230,10 @@ struct utm_ctx {
     unsigned char *d_state = nullptr;  // n_local
     double *d_weights = nullptr;       // n_total or null
     u64 *d_cnt = nullptr;              // n_local
+    u64 *d_cnt_alt = nullptr;          // persistent loop: the count words of odd iterations (loop_int.hip.h)
+    LoopSync *d_loop_sync = nullptr;   // ... its census counters and the picker's record
+    bool persist_off = false;          // ... a census failed on this context (not every block resident): launch per iteration from now on
+    i64 persist_launches = 0, persist_iterations = 0;  // statistics since the last utm_reset
     i64 *d_afsum = nullptr;            // n_local
     double *d_fscore = nullptr;        // n_local
     unsigned *d_act = nullptr;         // n_local
@@ -395,6 +399,9 @@ extern "C" int utm_ctx_create(int device, uint32_t n_samp_total, uint32_t first_
     HIP_TRY(hipMalloc(&c->d_act, ((size_t)n_samp_local + UTM_PICK_PAD) * 4));
     HIP_TRY(hipMemsetAsync(c->d_act, 0, ((size_t)n_samp_local + UTM_PICK_PAD) * 4, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, ((size_t)n_samp_local + UTM_PICK_PAD) * 8, c->stream));
+    HIP_TRY(hipMalloc(&c->d_cnt_alt, ((size_t)n_samp_local + UTM_PICK_PAD) * 8));
+    HIP_TRY(hipMemsetAsync(c->d_cnt_alt, 0, ((size_t)n_samp_local + UTM_PICK_PAD) * 8, c->stream));
+    HIP_TRY(hipMalloc(&c->d_loop_sync, sizeof(LoopSync)));
     HIP_TRY(hipMalloc(&c->d_varcount, (size_t)n_samp_local * 8));
     HIP_TRY(hipMalloc(&c->d_st, sizeof(IterState)));
     HIP_TRY(hipHostMalloc(&c->h_st, sizeof(IterState)));
@@ -449,6 +456,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
+    (void)hipFree(c->d_cnt_alt); (void)hipFree(c->d_loop_sync);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
     (void)hipFree(c->d_xbuf); (void)hipFree(c->d_wincol); (void)hipFree(c->d_stage); (void)hipFree(c->d_seq); (void)hipFree(c->d_seq_alt); (void)hipFree(c->d_varcount);
