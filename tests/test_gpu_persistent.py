@@ -103,6 +103,19 @@ def test_persistent_loop_with_few_resident_blocks_and_the_larger_tile(dev, wgs_p
         run_both(dev, dense, k=12)
 
 
+@pytest.mark.parametrize("n_var,n_samp,wgs", [(5_000, 2_000, "1"), (70_000, 3_000, "1"), (20_000, 9_000, "2"), (600_000, 1_100, "1")])
+def test_persistent_loop_claims_positions_dynamically(dev, n_var, n_samp, wgs, monkeypatch):
+    """More selectable samples than wave slots (few resident blocks): the positions behind every wave's static one are
+    claimed from the tiles' counters -- every (position, tile) partial exactly once, every iteration."""
+    monkeypatch.setenv("UTM_PERSIST_WGS_PER_CU", wgs)
+    rng = np.random.default_rng(n_var + n_samp)
+    dense = ou.random_dense(rng, n_var, n_samp, density=0.01)
+    state = np.ones(n_samp, np.uint8)
+    state[rng.choice(n_samp, n_samp // 10, replace=False)] = 2
+    st = run_both(dev, dense, state, k=min(n_samp, 600))
+    assert st["persist_iterations"] == st["iterations"] > 0
+
+
 def test_withheld_partial_count_ends_in_an_error_and_the_context_recovers(dev, monkeypatch):
     """the pick's bounded wait.  UTM_TEST_DROP_ARRIVAL=n withholds one partial count in the n-th iteration
     of a persistent launch (or the n-th scoring launch): the picker gives up after its spin budget, the loop ends with

@@ -152,7 +152,7 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
 struct LoopShape {
     bool ok = false;
     int steps = 8;
-    unsigned q_slots = 0, n_units = 0, per_xcd = 0;
+    unsigned q_slots = 0, n_tiles = 0;
 };
 static LoopShape loop_shape(utm_ctx *c)
 {
@@ -167,25 +167,24 @@ static LoopShape loop_shape(utm_ctx *c)
     if (!cus) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return sh;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, k_loop_int<8, true>, 256, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, k_loop_int<16, true>, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, k_loop_int<8, true>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, k_loop_int<16, true>, UTM_LOOP_THREADS, 0);
         cus = prop.multiProcessorCount;
+        if (getenv("UTM_VERBOSE")) fprintf(stderr, "libutmos_hip: k_loop_int occupancy query: %d (8 KiB tile) / %d (16 KiB tile) blocks of %d threads per CU, %d CUs\n", occ8, occ16, UTM_LOOP_THREADS, cus);
     }
     const u64 steps_total = ch.wp / UTM_STEP_WORDS;
     for (int steps : {8, 16}) {
-        int per_cu = std::min(steps == 8 ? occ8 : occ16, 8);
-        if (tn.persist_wgs_per_cu > 0) per_cu = std::min(per_cu, tn.persist_wgs_per_cu);
+        int per_cu = std::min(steps == 8 ? occ8 : occ16, 2048 / UTM_LOOP_THREADS);
+        if (tn.persist_wgs_per_cu > 0) per_cu = tn.persist_wgs_per_cu;  // (an override, also upwards: the census decides whether the grid is resident)
         const u64 max_workers = (u64)cus * (u64)std::max(per_cu, 0);
         if (max_workers < 16) continue;
         const u64 tiles = (steps_total + steps - 1) / steps;
-        const u64 q = (max_workers - 8) / tiles;  // (the picker's block and the padding to whole XCD rounds come out of the same budget)
+        const u64 q = (max_workers - 1) / tiles;  // (the picker's block comes out of the same budget)
         if (q < (steps == 8 ? 2u : 1u)) continue;
         sh.ok = true;
         sh.steps = steps;
-        sh.q_slots = (unsigned)std::min<u64>(q, ((u64)c->n_local + 3) / 4);  // (more wave slots than samples would only idle)
-        sh.q_slots = std::max(1u, sh.q_slots);
-        sh.n_units = (unsigned)(tiles * sh.q_slots);
-        sh.per_xcd = (sh.n_units + 7) / 8;
+        sh.n_tiles = (unsigned)tiles;
+        sh.q_slots = (unsigned)std::max<u64>(1, std::min<u64>(q, ((u64)c->n_local + UTM_LOOP_WAVES - 1) / UTM_LOOP_WAVES));  // (more wave slots than samples would only idle)
         return sh;
     }
     return sh;
@@ -196,14 +195,24 @@ static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch)
 {
     const Chunk &ch = c->chunks[0];
     const bool use_nt = c->tune.nt_loads >= 0 ? c->tune.nt_loads != 0 : (u64)c->n_local * c->col_words * 8 > ((u64)c->tune.nt_min_mb << 20);
+    // position claim counters: [3 sets, iteration % 3][tiles][wave index], 128 B apart
+    const size_t claim_bytes = (size_t)3 * sh.n_tiles * UTM_LOOP_WAVES * UTM_CLAIM_STRIDE * sizeof(unsigned);
+    if (c->claim_bytes < claim_bytes) {
+        (void)hipFree(c->d_claim);
+        c->d_claim = nullptr;
+        c->claim_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_claim, claim_bytes));
+        c->claim_bytes = claim_bytes;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_claim, 0, claim_bytes, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_loop_sync, 0, sizeof(LoopSync), c->stream));
     const PickArgs pa = pick_args(c);
-    const dim3 grid(8 * sh.per_xcd + 1);
+    const dim3 grid(sh.n_tiles * sh.q_slots + 1);
     const int drop = c->tune.test_drop_arrival;
     LaunchTimer t(c);
 #define UTM_LAUNCH_LOOP(S, NT)                                                                                                      \
-    UTM_TIMED_LAUNCH(t, (k_loop_int<S, NT>), grid, dim3(256), (const u64 *)ch.cols, ch.covered, ch.wp, pending_of(c, ch, true), c->d_st, \
-                     c->d_act, c->d_cnt, c->d_cnt_alt, sh.q_slots, sh.n_units, sh.per_xcd, k_batch, c->d_loop_sync, pa, drop)
+    UTM_TIMED_LAUNCH(t, (k_loop_int<S, NT>), grid, dim3(UTM_LOOP_THREADS), (const u64 *)ch.cols, ch.covered, ch.wp, pending_of(c, ch, true), c->d_st, \
+                     c->d_act, c->d_cnt, c->d_cnt_alt, sh.q_slots, c->d_claim, k_batch, c->d_loop_sync, pa, drop, c->tune.persist_claims, c->tune.persist_ahead_ticks, c->tune.persist_ahead0_ticks)
     if (sh.steps == 8) {
         if (use_nt) UTM_LAUNCH_LOOP(8, true);
         else UTM_LAUNCH_LOOP(8, false);
@@ -797,6 +806,14 @@ extern "C" int utm_set_profile(utm_ctx *c, int32_t on)
 }
 
 #ifdef UTM_DEBUG_STAMPS
+extern "C" int utm_dbg_loop_stamps(utm_ctx *c, uint64_t *out /* 256 x 8 */, uint64_t *wave_t /* 2 x 8192 */)
+{
+    std::vector<LoopSync> h(1);
+    HIP_TRY(copy_sync(c, h.data(), c->d_loop_sync, sizeof(LoopSync), hipMemcpyDeviceToHost));
+    memcpy(out, h[0].stamps, sizeof h[0].stamps);
+    if (wave_t) memcpy(wave_t, h[0].wave_t, sizeof h[0].wave_t);
+    return UTM_OK;
+}
 extern "C" int utm_dbg_verify_stamps(utm_ctx *c, uint64_t *out)
 {
     VerifySync h;

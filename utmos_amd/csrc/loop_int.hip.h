@@ -45,9 +45,28 @@ struct LoopSync {
     unsigned go;              // the picker's census verdict: 1 go, 2 abort
     unsigned worker_timeout;  // a worker gave up waiting for a record (diagnostic)
     unsigned pad1[30];
+#ifdef UTM_DEBUG_STAMPS
+    // per iteration of the launch (s_memrealtime, 10 ns ticks): 0 picker saw every count word complete, 1 record published,
+    // 2 block 1 / wave 0 finished its positions, 3 ... saw the record, 4 ... tile updated, 5 latest partial count of any
+    // wave (atomic max), 6 block 1 / wave 0 first batch of the next iteration counted
+    u64 stamps[256][8];
+    u64 wave_t[2][8192];  // iteration UTM_STAMP_ITER of the launch: every wave's [0] tile-ready and [1] last-partial times
+#endif
 };
+#define UTM_STAMP_ITER 100
+#ifdef UTM_DEBUG_STAMPS
+#define UTM_LSTAMP(sync, k, slot) (sync)->stamps[(k) & 255][slot] = (u64)wall_clock64()
+#else
+#define UTM_LSTAMP(sync, k, slot) (void)0
+#endif
 static_assert(sizeof(LoopSync) % 16 == 0, "zeroed by one memset");
 
+#define UTM_LOOP_THREADS 512  // 8 waves share a worker's tile; the picker's 512 threads cover 2,560 count words 5 apiece
+#define UTM_LOOP_WAVES (UTM_LOOP_THREADS / 64)
+#ifndef UTM_LOOP_E
+#define UTM_LOOP_E 5  // count words a picker thread keeps in flight (x UTM_LOOP_THREADS = one chunk)
+#endif
+#define UTM_CLAIM_STRIDE 32  // claim counters are 128 B apart
 #define UTM_LOOP_EPOCH_MASK 0xFFFFFFull
 #define UTM_LOOP_MAX_LOCAL (1u << 28)    // best_pos / moved are 28-bit fields
 #define UTM_LOOP_CENSUS_SPINS (1u << 12) // x s_sleep(32): ~3.5 ms before a missing block aborts the launch
@@ -76,9 +95,10 @@ __device__ __forceinline__ LoopRec loop_read_record(const LoopSync *sync, unsign
 
 // ------------------------------------------------------------------------------------------------ the picker
 struct LoopPickLds {
-    IntCand wbest[4];
+    IntCand wbest[UTM_LOOP_WAVES];
     unsigned n_active;
     int stop, failed, pad;
+    unsigned best_pos, moved;  // the decision's change to act[] (every thread keeps its own entries current)
 };
 
 __device__ __forceinline__ void loop_publish(LoopSync *sync, unsigned epoch, int stop, int removed, unsigned winner, unsigned best_pos,
@@ -90,8 +110,8 @@ __device__ __forceinline__ void loop_publish(LoopSync *sync, unsigned epoch, int
     __hip_atomic_store(&sync->pub[0], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u64 *cnt0, u64 *cnt1, unsigned n_tiles, unsigned n_blocks,
-                                            int k_batch, LoopPickLds *L)
+__device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u64 *cnt0, u64 *cnt1, unsigned *claim, unsigned n_tiles,
+                                            unsigned n_blocks, int k_batch, LoopPickLds *L)
 {
     IterState *st = a.st;
     const int lane = threadIdx.x & 63;
@@ -123,37 +143,48 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
         last_act = n_active ? __hip_atomic_load(&a.act[n_active - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     }
     const u64 count_mask = (1ull << UTM_ARRIVAL_SHIFT) - 1;
-    u64 t_pub = wall_clock64(), t_len = 0;  // when the last record went out; how long the iteration before it took (100 MHz ticks)
+    // all selectable samples within one chunk of count words (2,560): act[] is read once, then kept up to date from the
+    // decisions themselves -- a picker iteration then starts polling without a round trip to memory
+    const bool one_chunk = n_active <= UTM_LOOP_THREADS * UTM_LOOP_E;
+    unsigned s[UTM_LOOP_E];
+#pragma unroll
+    for (int e = 0; e < UTM_LOOP_E; ++e) s[e] = 0;
+    u64 t_pub = wall_clock64(), t_work = 0;  // when the last record went out; how long after ITS predecessor the last iteration's counts were complete (100 MHz ticks)
     for (int k = 0;; ++k) {
         u64 *cnt = (k & 1) ? cnt1 : cnt0;
         // Stay off the memory system while the iteration is certainly still running: polling all launch long costs the
-        // streaming waves bandwidth.  Iterations shrink slowly, so 3/4 of the last one's length is a safe nap.
-        if (t_len > 40) {
-            const u64 until = t_pub + t_len * 3 / 4;
+        // streaming waves bandwidth.  Iterations shrink slowly (one column fewer each time), so the counts are not
+        // complete before the last iteration's were, minus a margin; short iterations are polled from the start.
+        if (t_work > 1200) {
+            const u64 until = t_pub + t_work - 800;
             while ((u64)wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
         }
         IntCand best{0, 0xFFFFFFFFu, 0};
         int failed = 0;
-        for (unsigned base = 0; base < n_active && !failed; base += 256 * UTM_FUSED_E) {
+        // UTM_LOOP_E words per thread in flight, EVERY incomplete word of the chunk re-read every round: once the last
+        // partial has landed, the next round sees the chunk complete (2,504 samples are one chunk)
+        for (unsigned base = 0; base < n_active && !failed; base += UTM_LOOP_THREADS * UTM_LOOP_E) {
             const unsigned i0 = base + threadIdx.x;
-            unsigned s[UTM_FUSED_E];
             unsigned need = 0;
 #pragma unroll
-            for (int e = 0; e < UTM_FUSED_E; ++e) {  // (act[] and cnt[] carry UTM_PICK_PAD spare entries)
-                s[e] = __hip_atomic_load(&a.act[i0 + e * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (i0 + e * 256 < n_active) need |= 1u << e;
+            for (int e = 0; e < UTM_LOOP_E; ++e) {
+                const unsigned i = i0 + e * UTM_LOOP_THREADS;
+                const bool in = i < n_active;
+                // (one chunk: this thread's entries of act[] stay in its registers from iteration to iteration, see below)
+                if (!one_chunk || k == 0) s[e] = in ? __hip_atomic_load(&a.act[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                if (in) need |= 1u << e;
             }
             u64 *words = cnt + i0;
             for (unsigned spin = 0; need; ++spin) {
-                u64 v[UTM_FUSED_E];
+                u64 v[UTM_LOOP_E];
 #pragma unroll
-                for (int e = 0; e < UTM_FUSED_E; ++e)
-                    v[e] = __hip_atomic_fetch_add(words + e * 256, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int e = 0; e < UTM_LOOP_E; ++e)
+                    v[e] = (need >> e & 1) ? __hip_atomic_fetch_add(words + e * UTM_LOOP_THREADS, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
-                for (int e = 0; e < UTM_FUSED_E; ++e) {
+                for (int e = 0; e < UTM_LOOP_E; ++e) {
                     const bool fin = (need >> e & 1) && (v[e] >> UTM_ARRIVAL_SHIFT) == n_tiles;
-                    if (fin) __hip_atomic_store(words + e * 256, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (next used two iterations on)
-                    const IntCand cand{fin ? (v[e] & count_mask) : 0ull, fin ? s[e] : 0xFFFFFFFFu, i0 + e * 256};
+                    if (fin) __hip_atomic_store(words + e * UTM_LOOP_THREADS, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (next used two iterations on)
+                    const IntCand cand{fin ? (v[e] & count_mask) : 0ull, fin ? s[e] : 0xFFFFFFFFu, i0 + e * UTM_LOOP_THREADS};
                     if (better_int(cand, best)) best = cand;
                     need &= ~((fin ? 1u : 0u) << e);
                 }
@@ -171,7 +202,9 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
             other.pos = __shfl_xor(best.pos, o, 64);
             if (better_int(other, best)) best = other;
         }
+        t_work = (u64)wall_clock64() - t_pub;  // (this thread's words; all threads finish within a round of each other)
         if (threadIdx.x == 0) L->failed = 0;
+        if (threadIdx.x == 0) UTM_LSTAMP(sync, k, 0);
         __syncthreads();
         if (lane == 0) L->wbest[threadIdx.x >> 6] = best;
         if (failed) L->failed = 1;
@@ -179,14 +212,15 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
         if (threadIdx.x == 0) {
             const unsigned epoch = (unsigned)k + 1;
             int stop = 0;
+            unsigned last_act_used = 0;
             if (L->failed) {
                 st->xerror = 2;  // a partial count never arrived (a logic error, not a data condition)
                 st->done = 1;
                 stop = 1;
                 loop_publish(sync, epoch, 1, 0, 0, 0, 0);
             } else {
-                for (int w4 = 1; w4 < 4; ++w4)
-                    if (better_int(L->wbest[w4], best)) best = L->wbest[w4];
+                for (int w8 = 1; w8 < UTM_LOOP_WAVES; ++w8)
+                    if (better_int(L->wbest[w8], best)) best = L->wbest[w8];
                 // decide_single, on the loop state this thread carries in registers
                 if (n_active == 0 || best.cnt == 0) {  // (unweighted integer scores are never negative)
                     st->done = 1;  // (None, None): no row (select.py:51-52, :93-96)
@@ -195,6 +229,7 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                     loop_publish(sync, epoch, 1, 0, 0, 0, 0);
                 } else {
                     const unsigned moved = last_act;
+                    last_act_used = moved;
                     const int finished = tot + (i64)best.cnt >= a.n_var_total;  // "Ran out of new variants" (select.py:110-112)
                     stop = finished || k + 1 >= k_batch;
                     // the record first: everything below is bookkeeping nobody inside the launch waits for
@@ -234,31 +269,52 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
             }
             L->n_active = n_active;
             L->stop = stop;
+            L->best_pos = best.pos;
+            L->moved = last_act_used;
+            UTM_LSTAMP(sync, k, 1);
         }
+        // every count word of iteration k is complete => every claim of iteration k has come back (a wave waits for its
+        // claims before its last partial count): its counters can go back to 0.  THREE sets in turn (k % 3): a wave takes
+        // its first ticket of iteration k + 1 while iteration k is still running, from the set that was cleared after
+        // iteration k - 2 -- a whole iteration (and this block's vmcnt(0) below) earlier
+        for (unsigned t = threadIdx.x; t < n_tiles * UTM_LOOP_WAVES; t += UTM_LOOP_THREADS)
+            __hip_atomic_store(claim + ((size_t)(k % 3) * n_tiles * UTM_LOOP_WAVES + t) * UTM_CLAIM_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // this thread's clearing stores (and thread 0's act[] store) have landed before anybody reads those words again
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const u64 now = wall_clock64();
-        t_len = now - t_pub;
-        t_pub = now;
+        t_pub = wall_clock64();
         __syncthreads();
         if (L->stop) return;
         n_active = L->n_active;
+        if (one_chunk) {
+            const unsigned bp = L->best_pos, mv = L->moved;
+#pragma unroll
+            for (int e = 0; e < UTM_LOOP_E; ++e)
+                if (threadIdx.x + e * UTM_LOOP_THREADS == bp) s[e] = mv;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ the launch
-// Grid = 1 + 8 * per_xcd blocks of 256 threads: block 0 picks; block b > 0 sits (placement observed, speed only) on XCD
-// slot x = b & 7 and is that slot's j-th worker; unit u = x * per_xcd + j = (tile, slot) tile-major, so an XCD's workers
-// share few tiles and a winner's tile is fetched into ONE L2.  drop_iter: test hook (0 = off) -- the first worker
-// withholds one partial count in that iteration of the launch, so that the picker's bounded wait runs out.
+// Grid = 1 + n_tiles * Q blocks of 256 threads: block 0 picks; worker w = blockIdx.x - 1 owns tile w % n_tiles, slot
+// w / n_tiles -- a tile's workers are spread over all XCDs and over all dispatch ages (measured: a CU serves its oldest
+// waves first and the XCDs differ by up to 18 % in speed, so statically equal shares finished up to a third of an
+// iteration apart).  Positions: every wave has ONE static position, first = 4 * slot + wave (< 4Q: the one it holds
+// data for across the hand-off); the positions from 4Q on are CLAIMED, one at a time, from the tile's four counters
+// (one per wave index: position = 4Q + 4 * ticket + wave), so fast waves take more and a tile's waves finish together.
+// A claim is issued before the column loads of the position in front of it, so its round trip hides behind them; a
+// wave issues no claim after the one that came back out of range, and waits for every claim before its last partial
+// count -- which is why the picker may reset an iteration's counters as soon as all its count words are complete.
+// drop_iter: test hook (0 = off) -- the first worker withholds one partial count in that iteration of the launch, so
+// that the picker's bounded wait runs out.
 template <int STEPS, bool NT>
-__global__ __launch_bounds__(256) void k_loop_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp, const Pending pend,
+__global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp, const Pending pend,
                                                   IterState *__restrict__ st, unsigned *__restrict__ act, u64 *__restrict__ cnt0,
-                                                  u64 *__restrict__ cnt1, unsigned q_slots, unsigned n_units, unsigned per_xcd, int k_batch,
-                                                  LoopSync *__restrict__ sync, const PickArgs pa, int drop_iter)
+                                                  u64 *__restrict__ cnt1, unsigned q_slots, unsigned *__restrict__ claim, int k_batch,
+                                                  LoopSync *__restrict__ sync, const PickArgs pa, int drop_iter, int use_claims, int ahead_ticks, int ahead0_ticks)
 {
     __shared__ v4u live[STEPS * 64];  // ~covered of this worker's tile, for the whole launch
     __shared__ LoopRec rec_lds;
+    __shared__ unsigned rec_epoch_lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     typedef unsigned v8u __attribute__((ext_vector_type(8)));
     v8u raw;
@@ -268,15 +324,12 @@ __global__ __launch_bounds__(256) void k_loop_int(const u64 *__restrict__ cols, 
     constexpr unsigned TILE_WORDS = STEPS * UTM_STEP_WORDS;
     const unsigned n_tiles = (unsigned)((wp + TILE_WORDS - 1) / TILE_WORDS);
     if (blockIdx.x == 0) {
-        loop_picker(pa, sync, cnt0, cnt1, n_tiles, gridDim.x, k_batch, reinterpret_cast<LoopPickLds *>(&live[0]));
+        loop_picker(pa, sync, cnt0, cnt1, claim, n_tiles, gridDim.x, k_batch, reinterpret_cast<LoopPickLds *>(&live[0]));
         return;
     }
-    const unsigned xs = blockIdx.x & 7;
-    const unsigned j = (blockIdx.x >> 3) - (xs == 0 ? 1u : 0u);
-    const unsigned u = xs * per_xcd + j;
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync->arrive[xs * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (u >= n_units) return;  // (padding of the grid to whole XCD rounds: counted in, nothing to do)
-    const unsigned tile = u / q_slots, slot = u % q_slots;
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync->arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned w = blockIdx.x - 1;
+    const unsigned tile = w % n_tiles, slot = w / n_tiles;
     const u64 w0 = (u64)tile * TILE_WORDS;
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
     const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
@@ -284,47 +337,52 @@ __global__ __launch_bounds__(256) void k_loop_int(const u64 *__restrict__ cols, 
     constexpr int U = STEPS < 8 ? STEPS : 8;
 #define UTM_COL_LOAD(ptr) (NT ? __builtin_nontemporal_load(ptr) : *(ptr))
     const v4u zero4 = {0, 0, 0, 0};
-#define UTM_BATCH_LOAD(J0)                                                                 \
+    // One batch = U KiB of a column into buffer X from pointer P (full tiles: immediate offsets; the ragged last tile
+    // re-reads its last KiB for the missing steps and counts them as zero -- as in k_score_int).
+#define UTM_BATCH_LOAD(X, P, J0)                                                           \
     if (full) {                                                                            \
-        _Pragma("unroll") for (int q = 0; q < U; ++q) x[q] = UTM_COL_LOAD(p + ((J0) + q) * 64); \
+        _Pragma("unroll") for (int q = 0; q < U; ++q) X[q] = UTM_COL_LOAD((P) + ((J0) + q) * 64); \
     } else {                                                                               \
         _Pragma("unroll") for (int q = 0; q < U; ++q)                                      \
         {                                                                                  \
             const int step = (J0) + q;                                                     \
-            x[q] = UTM_COL_LOAD(p + (step < nsteps ? step : nsteps - 1) * 64);             \
+            X[q] = UTM_COL_LOAD((P) + (step < nsteps ? step : nsteps - 1) * 64);           \
         }                                                                                  \
     }
-#define UTM_BATCH_COUNT(J0)                                                                \
+#define UTM_BATCH_COUNT(X, J0)                                                             \
     if (full) {                                                                            \
         _Pragma("unroll") for (int q = 0; q < U; ++q)                                      \
         {                                                                                  \
-            const v4u b = x[q] & live[((J0) + q) * 64 + lane];                             \
+            const v4u b = X[q] & live[((J0) + q) * 64 + lane];                             \
             acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                  \
         }                                                                                  \
     } else {                                                                               \
         _Pragma("unroll") for (int q = 0; q < U; ++q)                                      \
         {                                                                                  \
             const int step = (J0) + q;                                                     \
-            const v4u b = (step < nsteps ? x[q] : zero4) & live[(step < nsteps ? step : 0) * 64 + lane]; \
+            const v4u b = (step < nsteps ? X[q] : zero4) & live[(step < nsteps ? step : 0) * 64 + lane]; \
             acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                  \
         }                                                                                  \
     }
-    // this wave's positions of act[]: first, first + stride, ...
-    const unsigned first = slot * 4 + wave, stride = q_slots * 4;
+#define UTM_COL_PTR(S) (reinterpret_cast<const v4u *>(cols + (u64)(S) * wp + w0) + lane)
+    // Two STATIC positions per wave -- first and second = first + 8Q -- whose first batches a wave holds in registers
+    // across the hand-off (x0, x1: 16 KiB of run-ahead per wave); everything from 16Q on is claimed.
+    const unsigned stride = q_slots * UTM_LOOP_WAVES;
+    const unsigned first = slot * UTM_LOOP_WAVES + wave, second = first + stride, dyn0 = 2 * stride;
     unsigned n_act = head.n_active;
     const unsigned act_cap = pa.n_local + UTM_PICK_PAD;  // (entries that may be read ahead of the bounds that say whether they count)
     unsigned s_first = first < act_cap ? act[first] : 0u;  // (act[] is as the host / the last launch left it: plain loads)
-    unsigned s_next = first + stride < act_cap ? act[first + stride] : 0u;
-    const v4u *p = reinterpret_cast<const v4u *>(cols + (u64)s_first * wp + w0) + lane;
-    v4u x[U];
-    if (first < n_act) { UTM_BATCH_LOAD(0) }
+    unsigned s_second = second < act_cap ? act[second] : 0u;
+    v4u x0[U], x1[U];
+    if (first < n_act) { UTM_BATCH_LOAD(x0, UTM_COL_PTR(s_first), 0) }
+    if (second < n_act) { UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0) }
 
-    // stage ~(covered | pending winner) once; slot 0 brings covered itself up to date
+    // stage ~(covered | pending winner) once
     {
-        v4u *cv = reinterpret_cast<v4u *>(covered + w0);
+        const v4u *cv = reinterpret_cast<const v4u *>(covered + w0);
         const u64 *wcol = pend.fuse ? pending_column(&head, cols, wp, pend) : nullptr;
         const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
-        for (int k = threadIdx.x; k < nsteps * 64; k += 256) {
+        for (int k = threadIdx.x; k < nsteps * 64; k += UTM_LOOP_THREADS) {
             v4u c = cv[k];
             if (wc) c |= wc[k];
             live[k] = ~c;
@@ -339,40 +397,109 @@ __global__ __launch_bounds__(256) void k_loop_int(const u64 *__restrict__ cols, 
             __builtin_amdgcn_s_sleep(8);
         }
         rec_lds.ok = g == 1;
+        rec_epoch_lds = 0;
     }
     __syncthreads();
     if (!rec_lds.ok) return;  // abort (or no verdict): nothing has been written
 
+    bool have_spec = false;  // the first ticket of the coming iteration has been taken (and its sample read) ahead of the record
+    unsigned spec_ticket = 0, spec_s = 0;
+    u64 t_rec = 0, t_iter = 0;  // this wave's clock at the last record, and the interval between the last two (10 ns ticks)
     unsigned patch_pos = 0xFFFFFFFFu, patch_s = 0;  // the newest record's change to act[] (its store may still be in flight)
 #define UTM_ACT_LOAD(i) ((i) == patch_pos ? patch_s : __hip_atomic_load(&act[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    // (wave-uniform values fetched by vector instructions: moved to scalar registers)
+#define UTM_UNIFORM(v) ((unsigned)__builtin_amdgcn_readfirstlane((int)(v)))
+    // one ticket of this wave's counter: ONE lane adds; the value stays in that lane's register until it is needed
+    // (UTM_UNIFORM on it is the wait), so the column loads issued behind the claim are not held up by its round trip
+    auto take_ticket = [&](unsigned *counter) -> unsigned {
+        unsigned t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+    };
+#define UTM_PARTIAL(POS, ACC, DROP)                                                                                    \
+    {                                                                                                                  \
+        const unsigned sum_ = wave_sum_u32(ACC);                                                                       \
+        if (lane == 0 && !(DROP)) atomicAdd(&cnt[POS], (u64)sum_ + (1ull << UTM_ARRIVAL_SHIFT));                       \
+    }
     for (int k = 0;; ++k) {
         u64 *cnt = (k & 1) ? cnt1 : cnt0;
-        unsigned i = first, s = s_first;
-        while (i < n_act) {
-            unsigned acc = 0;
+        unsigned *my_claim = claim + ((size_t)((k % 3) * n_tiles + tile) * UTM_LOOP_WAVES + wave) * UTM_CLAIM_STRIDE;
+        if (first < n_act) {  // (x0 / x1 hold the first batches of the samples at `first` / `second`)
+            const bool dyn = use_claims && n_act > dyn0;  // (else every position is somebody's static one: no claims at all)
+            // the first ticket was taken ahead of the record (below); without one (first iteration of the launch) now
+            unsigned ticket = !dyn ? 0u : have_spec ? spec_ticket : take_ticket(my_claim);
+            bool spec_round = dyn && have_spec;  // ... and so was its sample read from act[]
+            if (second < n_act) {
+                unsigned acc = 0;
+                const v4u *p1 = UTM_COL_PTR(s_second);
 #pragma unroll 1
-            for (int j0 = 0; j0 < nsteps; j0 += U) {
-                if (j0) { UTM_BATCH_LOAD(j0) }
-                UTM_BATCH_COUNT(j0)
+                for (int j0 = 0; j0 < nsteps; j0 += U) {
+                    if (j0) { UTM_BATCH_LOAD(x1, p1, j0) }
+                    UTM_BATCH_COUNT(x1, j0)
+                }
+                UTM_PARTIAL(second, acc, false)
             }
-            const unsigned done_i = i;
-            i += stride;
-            s = s_next;
-            if (i < n_act) {
-                s_next = i + stride < n_act ? UTM_ACT_LOAD(i + stride) : 0u;
-                p = reinterpret_cast<const v4u *>(cols + (u64)s * wp + w0) + lane;
-                UTM_BATCH_LOAD(0)
+            unsigned cur = first, s = s_first;
+            const v4u *p = UTM_COL_PTR(s);
+            for (;;) {
+                // the claim was issued ahead of the column loads in flight, so it is back before them
+                // (use_claims == 0, an experiment switch: the positions behind the static two are dealt statically too)
+                const unsigned pos_n = dyn          ? dyn0 + (unsigned)UTM_LOOP_WAVES * UTM_UNIFORM(ticket) + (unsigned)wave
+                                       : use_claims ? 0xFFFFFFFFu
+                                                    : (cur == first ? first + dyn0 : cur + stride);
+                unsigned s_n = 0;  // (lands right behind the column loads: not waited for here)
+                if (pos_n < n_act) s_n = spec_round ? (pos_n == patch_pos ? patch_s : spec_s) : UTM_ACT_LOAD(pos_n);
+                spec_round = false;
+                unsigned acc = 0;
+#pragma unroll 1
+                for (int j0 = 0; j0 < nsteps; j0 += U) {
+                    if (j0) { UTM_BATCH_LOAD(x0, p, j0) }
+                    UTM_BATCH_COUNT(x0, j0)
+                }
+                const bool drop = drop_iter && k + 1 == drop_iter && blockIdx.x == 1 && wave == 0 && cur == first;
+                UTM_PARTIAL(cur, acc, drop)
+#ifdef UTM_DEBUG_STAMPS
+                if (lane == 0 && k > 0 && cur == first && blockIdx.x == 1 && wave == 0) UTM_LSTAMP(sync, k - 1, 6);
+#endif
+                if (pos_n >= n_act) break;  // (the one claim that came back out of range; none was issued behind it)
+                cur = pos_n;
+                s = UTM_UNIFORM(s_n);
+                if (dyn) ticket = take_ticket(my_claim);  // the next claim first, the loads behind it
+                p = UTM_COL_PTR(s);
+                UTM_BATCH_LOAD(x0, p, 0)
             }
-            acc = wave_sum_u32(acc);
-            const bool drop = drop_iter && k + 1 == drop_iter && blockIdx.x == 1 && done_i == first;
-            if (lane == 0 && !drop) atomicAdd(&cnt[done_i], (u64)acc + (1ull << UTM_ARRIVAL_SHIFT));
         }
-        // ahead of the record: the first 8 KiB of the next iteration.  The sample at `first` stays where it is unless
-        // the record names that very position (then it is loaded again below); a position that drops out costs one
-        // wasted batch.
-        p = reinterpret_cast<const v4u *>(cols + (u64)s_first * wp + w0) + lane;
-        if (first < n_act) { UTM_BATCH_LOAD(0) }
-        if (first + stride < n_act) s_next = UTM_ACT_LOAD(first + stride);
+#ifdef UTM_DEBUG_STAMPS
+        if (lane == 0 && k == UTM_STAMP_ITER && blockIdx.x * UTM_LOOP_WAVES + wave < 8192) sync->wave_t[1][blockIdx.x * UTM_LOOP_WAVES + wave] = (u64)wall_clock64();
+        if (blockIdx.x == 1 && threadIdx.x == 0) UTM_LSTAMP(sync, k, 2);
+#endif
+        // Ahead of the record: the first batches of the next iteration's two static positions.  Their samples stay where
+        // they are unless the record names one of those very positions (then it is loaded again below); a position that
+        // drops out of range costs one wasted batch.  These 16 KiB per wave are what keeps the memory pipes busy while
+        // the picker reduces, publishes, and the tile is brought up to date.
+        // The first batch goes out at once (it fills the tail of the iteration, while the slowest waves finish); the
+        // second is held back until `ahead` before the record is due -- iterations shrink smoothly, so the last interval
+        // between two records predicts this one -- so that it is still in flight when the record arrives.
+        // ... and ahead of everything: this wave's first ticket of the next iteration and that position's sample (both
+        // round trips are then off the path from the record to the first new column loads)
+        have_spec = use_claims && n_act > dyn0 + 1;
+        if (have_spec) {
+            unsigned *next_claim = claim + ((size_t)(((k + 1) % 3) * n_tiles + tile) * UTM_LOOP_WAVES + wave) * UTM_CLAIM_STRIDE;
+            spec_ticket = take_ticket(next_claim);
+            const unsigned pos_spec = dyn0 + (unsigned)UTM_LOOP_WAVES * UTM_UNIFORM(spec_ticket) + (unsigned)wave;
+            spec_s = pos_spec < act_cap ? UTM_ACT_LOAD(pos_spec) : 0u;
+        }
+        const u64 t_due0 = (ahead0_ticks && t_iter) ? t_rec + t_iter - (t_iter > (u64)ahead0_ticks ? (u64)ahead0_ticks : t_iter) : 0;
+        if (t_due0)
+            while ((u64)wall_clock64() < t_due0) __builtin_amdgcn_s_sleep(2);  // (experiment: the first batch held back too)
+        if (first < n_act) { UTM_BATCH_LOAD(x0, UTM_COL_PTR(s_first), 0) }
+        const u64 t_due = (ahead_ticks && t_iter) ? t_rec + t_iter - (t_iter > (u64)ahead_ticks ? (u64)ahead_ticks : t_iter) : 0;
+        bool second_out = false;
+        if (second >= n_act) second_out = true;
+        else if (!t_due || (u64)wall_clock64() >= t_due) {
+            UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0)
+            second_out = true;
+        }
 
         const unsigned epoch = (unsigned)k + 1;
         if (wave == 0) {
@@ -381,6 +508,10 @@ __global__ __launch_bounds__(256) void k_loop_int(const u64 *__restrict__ cols, 
             for (unsigned spin = 0; spin < UTM_LOOP_WAIT_SPINS; ++spin) {
                 r = loop_read_record(sync, epoch);
                 if (r.ok) break;
+                if (!second_out && (u64)wall_clock64() >= t_due) {
+                    UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0)
+                    second_out = true;
+                }
                 __builtin_amdgcn_s_sleep(4);
             }
             if (lane == 0) {
@@ -389,15 +520,22 @@ __global__ __launch_bounds__(256) void k_loop_int(const u64 *__restrict__ cols, 
                     __hip_atomic_store(&sync->worker_timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 rec_lds = r;
+                __hip_atomic_store(&rec_epoch_lds, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // wakes the other waves
+                if (blockIdx.x == 1) UTM_LSTAMP(sync, k, 3);
             }
+        } else if (!second_out) {
+            // (a timed wait on the wave's own clock; the record, should it come first, ends it)
+            while (__hip_atomic_load(&rec_epoch_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch && (u64)wall_clock64() < t_due)
+                __builtin_amdgcn_s_sleep(2);
         }
+        if (!second_out) { UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0) }
         __syncthreads();
         const LoopRec r = rec_lds;
         if (r.stop) break;  // (uniform) the launch ends here: the winner stays pending, exactly as after a k_score_int launch
         // covered |= winner, in LDS: live &= ~winner's tile
         {
             const v4u *wc = reinterpret_cast<const v4u *>(cols + (u64)r.winner * wp + w0);
-            for (int kk = threadIdx.x; kk < nsteps * 64; kk += 256) live[kk] &= ~wc[kk];
+            for (int kk = threadIdx.x; kk < nsteps * 64; kk += UTM_LOOP_THREADS) live[kk] &= ~wc[kk];
         }
         if (r.removed) {
             n_act -= 1;
@@ -405,18 +543,32 @@ __global__ __launch_bounds__(256) void k_loop_int(const u64 *__restrict__ cols, 
             patch_s = r.moved;
             if (first == r.best_pos) {
                 s_first = r.moved;
-                p = reinterpret_cast<const v4u *>(cols + (u64)s_first * wp + w0) + lane;
-                if (first < n_act) { UTM_BATCH_LOAD(0) }
+                if (first < n_act) { UTM_BATCH_LOAD(x0, UTM_COL_PTR(s_first), 0) }
             }
-            if (first + stride == r.best_pos) s_next = r.moved;
+            if (second == r.best_pos) {
+                s_second = r.moved;
+                if (second < n_act) { UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0) }
+            }
         }
         __syncthreads();  // the tile is whole again (and rec_lds may be rewritten)
+        {
+            const u64 now = (u64)wall_clock64();
+            t_iter = t_rec ? now - t_rec : 0;
+            t_rec = now;
+        }
+        if (blockIdx.x == 1 && threadIdx.x == 0) UTM_LSTAMP(sync, k, 4);
+#ifdef UTM_DEBUG_STAMPS
+        if (lane == 0 && k + 1 == UTM_STAMP_ITER && blockIdx.x * UTM_LOOP_WAVES + wave < 8192) sync->wave_t[0][blockIdx.x * UTM_LOOP_WAVES + wave] = (u64)wall_clock64();
+#endif
     }
     // the tile's covered words go back to memory (the pending winner is NOT in them: the next launch folds it in)
     if (slot == 0) {
         v4u *cv = reinterpret_cast<v4u *>(covered + w0);
-        for (int k = threadIdx.x; k < nsteps * 64; k += 256) cv[k] = ~live[k];
+        for (int k = threadIdx.x; k < nsteps * 64; k += UTM_LOOP_THREADS) cv[k] = ~live[k];
     }
+#undef UTM_PARTIAL
+#undef UTM_COL_PTR
+#undef UTM_UNIFORM
 #undef UTM_ACT_LOAD
 #undef UTM_COL_LOAD
 #undef UTM_BATCH_LOAD

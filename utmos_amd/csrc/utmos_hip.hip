@@ -126,7 +126,7 @@ struct Tune {
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
-    int persistent, persist_max_mb, persist_wgs_per_cu, test_drop_arrival;   // persistent loop kernel
+    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, test_drop_arrival;   // persistent loop kernel
 };
 struct KnobDef {
     const char *name;
@@ -161,6 +161,9 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_PERSISTENT", persistent, 1),
     UTM_KNOB_I("UTM_PERSIST_MAX_MB", persist_max_mb, 0),
     UTM_KNOB_I("UTM_PERSIST_WGS_PER_CU", persist_wgs_per_cu, 0),
+    UTM_KNOB_I("UTM_PERSIST_CLAIMS", persist_claims, 1),
+    UTM_KNOB_I("UTM_PERSIST_AHEAD0_TICKS", persist_ahead0_ticks, 0),
+    UTM_KNOB_I("UTM_PERSIST_AHEAD_TICKS", persist_ahead_ticks, 400),  // 10 ns ticks: the second run-ahead batch goes out this long before the record is due (0: at once)
     UTM_KNOB_I("UTM_TEST_DROP_ARRIVAL", test_drop_arrival, 0),
 };
 static void read_tune(Tune *t)
@@ -232,6 +235,8 @@ struct utm_ctx {
     u64 *d_cnt = nullptr;              // n_local
     u64 *d_cnt_alt = nullptr;          // persistent loop: the count words of odd iterations (loop_int.hip.h)
     LoopSync *d_loop_sync = nullptr;   // ... its census counters and the picker's record
+    unsigned *d_claim = nullptr;       // ... its position claim counters (sized for the tile grid at the first launch)
+    size_t claim_bytes = 0;
     bool persist_off = false;          // ... a census failed on this context (not every block resident): launch per iteration from now on
     i64 persist_launches = 0, persist_iterations = 0;  // statistics since the last utm_reset
     i64 *d_afsum = nullptr;            // n_local
@@ -456,7 +461,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
-    (void)hipFree(c->d_cnt_alt); (void)hipFree(c->d_loop_sync);
+    (void)hipFree(c->d_cnt_alt); (void)hipFree(c->d_loop_sync); (void)hipFree(c->d_claim);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
     (void)hipFree(c->d_xbuf); (void)hipFree(c->d_wincol); (void)hipFree(c->d_stage); (void)hipFree(c->d_seq); (void)hipFree(c->d_seq_alt); (void)hipFree(c->d_varcount);
