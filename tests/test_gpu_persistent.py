@@ -47,7 +47,7 @@ def run_both(dev, dense, state=None, k=None, pieces=None, monkeypatch=None):
 
 
 @pytest.mark.parametrize("n_var,n_samp", [(1, 1), (63, 3), (64, 4), (65, 5), (1000, 130), (8192, 64), (8193, 257), (70_000, 700),
-                                          (200_000, 37), (3_000, 3_000)])
+                                          (200_000, 37), (3_000, 2_500)])
 def test_persistent_loop_select_all(dev, n_var, n_samp):
     rng = np.random.default_rng(n_var * 31 + n_samp)
     st = run_both(dev, ou.random_dense(rng, n_var, n_samp))
@@ -90,20 +90,35 @@ def test_persistent_loop_states_ties_and_stops(dev):
     assert 1 <= st["iterations"] < 32
 
 
-@pytest.mark.parametrize("wgs_per_cu", ["1", "3"])
-def test_persistent_loop_with_few_resident_blocks_and_the_larger_tile(dev, wgs_per_cu, monkeypatch):
-    """UTM_PERSIST_WGS_PER_CU shrinks the grid: more variants than 8 KiB tiles x blocks -> the 16 KiB tile; and past that
-    the loop falls back to one launch per iteration (same rows)."""
-    monkeypatch.setenv("UTM_PERSIST_WGS_PER_CU", wgs_per_cu)
-    rng = np.random.default_rng(int(wgs_per_cu))
-    for n_var in (300_000, 9_000_000 if wgs_per_cu == "1" else 1_200_000):
-        n_samp = 40
-        dense = rng.random((n_var, n_samp)) < 0.05
-        dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
-        run_both(dev, dense, k=12)
+@pytest.mark.parametrize("tile_kib", ["16", "32", "64"])
+@pytest.mark.parametrize("n_var,n_samp", [(300_000, 300), (1_000_000, 90), (70_001, 1_500), (2_100_000, 40)])
+def test_persistent_loop_tiles_of_several_batches(dev, tile_kib, n_var, n_samp, monkeypatch):
+    """Tiles of 2 / 4 / 8 batches (taller matrices: fewer atomics per count word): a position's partial count goes out with
+    its last batch; short last tiles, tiles shorter than one batch, columns that end inside a batch; claimed positions
+    (few resident blocks)."""
+    monkeypatch.setenv("UTM_PERSIST_TILE_KIB", tile_kib)
+    monkeypatch.setenv("UTM_PERSIST_WGS_PER_CU", "1")
+    rng = np.random.default_rng(int(tile_kib) + n_samp)
+    dense = rng.random((n_var, n_samp)) < 0.03
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    st = run_both(dev, dense, k=min(n_samp, 40))
+    assert st["persist_iterations"] == st["iterations"] > 0
 
 
-@pytest.mark.parametrize("n_var,n_samp,wgs", [(5_000, 2_000, "1"), (70_000, 3_000, "1"), (20_000, 9_000, "2"), (600_000, 1_100, "1")])
+def test_persistent_loop_tile_is_chosen_by_the_matrix_height_and_tall_or_wide_matrices_keep_the_launches(dev, monkeypatch):
+    rng = np.random.default_rng(1)
+    monkeypatch.setenv("UTM_PERSIST_MAX_TILES", "4")
+    for n_var, expect in ((200_000, True), (1_900_000, True), (2_200_000, False)):      # 4 x 8 KiB ... 4 x 64 KiB tiles, then none
+        dense = rng.random((n_var, 24)) < 0.05
+        dense[np.arange(n_var), rng.integers(0, 24, n_var)] = True
+        st = run_both(dev, dense, k=6)
+        assert (st["persist_iterations"] > 0) == expect, (n_var, st)
+    monkeypatch.delenv("UTM_PERSIST_MAX_TILES")
+    st = run_both(dev, ou.random_dense(rng, 3_000, 3_000), k=20)                           # more samples than one picker chunk
+    assert st["persist_iterations"] == 0
+
+
+@pytest.mark.parametrize("n_var,n_samp,wgs", [(5_000, 2_000, "1"), (70_000, 2_500, "1"), (20_000, 2_300, "2"), (600_000, 1_100, "1")])
 def test_persistent_loop_claims_positions_dynamically(dev, n_var, n_samp, wgs, monkeypatch):
     """More selectable samples than wave slots (few resident blocks): the positions behind every wave's static one are
     claimed from the tiles' counters -- every (position, tile) partial exactly once, every iteration."""

@@ -15,7 +15,10 @@ extern "C" int utm_add_chunk(utm_ctx *c, uint64_t n_var, int32_t *chunk)
     ch.w = (n_var + 63) / 64;
     ch.wp = round_up(ch.w, UTM_STEP_WORDS);
     ch.off = c->col_words;
-    const size_t bytes = (size_t)c->n_local * ch.wp * 8;
+    // (+ 64 KiB of zeros behind the last column: the persistent loop reads whole 8 KiB batches, and the last batch of a
+    // column's last tile may run past the column's end -- into the next column, or here; those words are counted against
+    // zero words of the covered tile)
+    const size_t bytes = (size_t)c->n_local * ch.wp * 8 + UTM_COLS_SLACK_BYTES;
     HIP_TRY(hipMalloc(&ch.cols, bytes));
     HIP_TRY(hipMemsetAsync(ch.cols, 0, bytes, c->stream));
     HIP_TRY(hipMalloc(&ch.covered, ch.wp * 8));

@@ -67,6 +67,7 @@ static_assert(sizeof(LoopSync) % 16 == 0, "zeroed by one memset");
 #define UTM_LOOP_E 5  // count words a picker thread keeps in flight (x UTM_LOOP_THREADS = one chunk)
 #endif
 #define UTM_CLAIM_STRIDE 32  // claim counters are 128 B apart
+#define UTM_COLS_SLACK_BYTES (64u << 10)  // zeros behind a chunk's last column (whole-batch reads of a short last tile)
 #define UTM_LOOP_EPOCH_MASK 0xFFFFFFull
 #define UTM_LOOP_MAX_LOCAL (1u << 28)    // best_pos / moved are 28-bit fields
 #define UTM_LOOP_CENSUS_SPINS (1u << 12) // x s_sleep(32): ~3.5 ms before a missing block aborts the launch
@@ -307,12 +308,13 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
 // drop_iter: test hook (0 = off) -- the first worker withholds one partial count in that iteration of the launch, so
 // that the picker's bounded wait runs out.
 template <int STEPS, bool NT>
-__global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp, const Pending pend,
+__global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp, const Pending pend,
                                                   IterState *__restrict__ st, unsigned *__restrict__ act, u64 *__restrict__ cnt0,
                                                   u64 *__restrict__ cnt1, unsigned q_slots, unsigned *__restrict__ claim, int k_batch,
                                                   LoopSync *__restrict__ sync, const PickArgs pa, int drop_iter, int use_claims, int ahead_ticks, int ahead0_ticks)
 {
-    __shared__ v4u live[STEPS * 64];  // ~covered of this worker's tile, for the whole launch
+    static_assert(STEPS % 8 == 0 && STEPS <= 64, "a tile is 1..8 batches of 8 KiB");
+    __shared__ v4u live[STEPS * 64];  // ~covered of this worker's tile (STEPS KiB), for the whole launch
     __shared__ LoopRec rec_lds;
     __shared__ unsigned rec_epoch_lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -332,41 +334,32 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
     const unsigned tile = w % n_tiles, slot = w / n_tiles;
     const u64 w0 = (u64)tile * TILE_WORDS;
     const u64 left = (wp - w0) / UTM_STEP_WORDS;
-    const int nsteps = left < (u64)STEPS ? (int)left : STEPS;
-    const bool full = nsteps == STEPS;
-    constexpr int U = STEPS < 8 ? STEPS : 8;
+    const int nsteps = left < (u64)STEPS ? (int)left : STEPS;  // KiB of this tile (the last tile of a column may be short)
+    const int nb = STEPS == 8 ? 1 : (nsteps + 7) / 8;          // ... in batches of 8 KiB: what a wave has in flight per buffer
+                                                               // (the 8 KiB tile: a compile-time 1, and every batch index below a 0)
+    constexpr int U = 8;
 #define UTM_COL_LOAD(ptr) (NT ? __builtin_nontemporal_load(ptr) : *(ptr))
-    const v4u zero4 = {0, 0, 0, 0};
-    // One batch = U KiB of a column into buffer X from pointer P (full tiles: immediate offsets; the ragged last tile
-    // re-reads its last KiB for the missing steps and counts them as zero -- as in k_score_int).
-#define UTM_BATCH_LOAD(X, P, J0)                                                           \
-    if (full) {                                                                            \
-        _Pragma("unroll") for (int q = 0; q < U; ++q) X[q] = UTM_COL_LOAD((P) + ((J0) + q) * 64); \
-    } else {                                                                               \
-        _Pragma("unroll") for (int q = 0; q < U; ++q)                                      \
-        {                                                                                  \
-            const int step = (J0) + q;                                                     \
-            X[q] = UTM_COL_LOAD((P) + (step < nsteps ? step : nsteps - 1) * 64);           \
-        }                                                                                  \
+    // Batch J (8 KiB) of a sample's tile-column into buffer X: one base address, immediate offsets.  A column's last tile
+    // may end inside a batch: the loads then run on into the next column (or the slack behind the matrix,
+    // UTM_COLS_SLACK_BYTES) and those words are counted against zero words of the LDS tile -- one code path, no clamps.
+#define UTM_BATCH_LOAD(X, S, J)                                                                      \
+    {                                                                                                \
+        const v4u *p_ = reinterpret_cast<const v4u *>(cols + (u64)(S) * wp + w0) + (J) * 8 * 64 + lane; \
+        _Pragma("unroll") for (int q = 0; q < U; ++q) X[q] = UTM_COL_LOAD(p_ + q * 64);              \
     }
-#define UTM_BATCH_COUNT(X, J0)                                                             \
-    if (full) {                                                                            \
-        _Pragma("unroll") for (int q = 0; q < U; ++q)                                      \
-        {                                                                                  \
-            const v4u b = X[q] & live[((J0) + q) * 64 + lane];                             \
-            acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                  \
-        }                                                                                  \
-    } else {                                                                               \
-        _Pragma("unroll") for (int q = 0; q < U; ++q)                                      \
-        {                                                                                  \
-            const int step = (J0) + q;                                                     \
-            const v4u b = (step < nsteps ? X[q] : zero4) & live[(step < nsteps ? step : 0) * 64 + lane]; \
-            acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                  \
-        }                                                                                  \
+#define UTM_BATCH_COUNT(X, J)                                                                        \
+    {                                                                                                \
+        const v4u *l_ = &live[(J) * 8 * 64 + lane];                                                  \
+        _Pragma("unroll") for (int q = 0; q < U; ++q)                                                \
+        {                                                                                            \
+            const v4u b = X[q] & l_[q * 64];                                                         \
+            acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                            \
+        }                                                                                            \
     }
-#define UTM_COL_PTR(S) (reinterpret_cast<const v4u *>(cols + (u64)(S) * wp + w0) + lane)
-    // Two STATIC positions per wave -- first and second = first + 8Q -- whose first batches a wave holds in registers
-    // across the hand-off (x0, x1: 16 KiB of run-ahead per wave); everything from 16Q on is claimed.
+    // A wave's work in an iteration is a STREAM of batches: all nb batches of its first position, of its second, then of
+    // the positions it claims.  first = 8 * slot + wave and second = first + 8Q are static; the positions from 16Q on are
+    // claimed.  Two batches are in flight at any time (x0, x1 in turn) -- and across the hand-off: the first two batches
+    // of the next iteration's stream are what a wave holds while the picker decides.
     const unsigned stride = q_slots * UTM_LOOP_WAVES;
     const unsigned first = slot * UTM_LOOP_WAVES + wave, second = first + stride, dyn0 = 2 * stride;
     unsigned n_act = head.n_active;
@@ -374,8 +367,13 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
     unsigned s_first = first < act_cap ? act[first] : 0u;  // (act[] is as the host / the last launch left it: plain loads)
     unsigned s_second = second < act_cap ? act[second] : 0u;
     v4u x0[U], x1[U];
-    if (first < n_act) { UTM_BATCH_LOAD(x0, UTM_COL_PTR(s_first), 0) }
-    if (second < n_act) { UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0) }
+    // the stream's first two batches: (first, 0) and then (first, 1), or (second, 0) where a tile is one batch
+#define UTM_AHEAD0() if (first < n_act) { UTM_BATCH_LOAD(x0, s_first, 0) }
+#define UTM_AHEAD1()                                                         \
+    if (nb > 1) { if (first < n_act) { UTM_BATCH_LOAD(x1, s_first, 1) } }    \
+    else if (second < n_act) { UTM_BATCH_LOAD(x1, s_second, 0) }
+    UTM_AHEAD0()
+    UTM_AHEAD1()
 
     // stage ~(covered | pending winner) once
     {
@@ -387,6 +385,8 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
             if (wc) c |= wc[k];
             live[k] = ~c;
         }
+        const v4u zero4 = {0, 0, 0, 0};
+        for (int k = nsteps * 64 + threadIdx.x; k < STEPS * 64; k += UTM_LOOP_THREADS) live[k] = zero4;  // (a short tile's missing steps)
     }
     // the census verdict
     if (threadIdx.x == 0) {
@@ -403,7 +403,8 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
     if (!rec_lds.ok) return;  // abort (or no verdict): nothing has been written
 
     bool have_spec = false;  // the first ticket of the coming iteration has been taken (and its sample read) ahead of the record
-    unsigned spec_ticket = 0, spec_s = 0;
+    unsigned spec_ticket = 0, spec_s = 0, spec_ticket2 = 0;
+    bool spec2_out = false;  // ... and a second one is in flight
     u64 t_rec = 0, t_iter = 0;  // this wave's clock at the last record, and the interval between the last two (10 ns ticks)
     unsigned patch_pos = 0xFFFFFFFFu, patch_s = 0;  // the newest record's change to act[] (its store may still be in flight)
 #define UTM_ACT_LOAD(i) ((i) == patch_pos ? patch_s : __hip_atomic_load(&act[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -421,83 +422,151 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
         const unsigned sum_ = wave_sum_u32(ACC);                                                                       \
         if (lane == 0 && !(DROP)) atomicAdd(&cnt[POS], (u64)sum_ + (1ull << UTM_ARRIVAL_SHIFT));                       \
     }
+    const unsigned none = 0xFFFFFFFFu;
     for (int k = 0;; ++k) {
         u64 *cnt = (k & 1) ? cnt1 : cnt0;
         unsigned *my_claim = claim + ((size_t)((k % 3) * n_tiles + tile) * UTM_LOOP_WAVES + wave) * UTM_CLAIM_STRIDE;
-        if (first < n_act) {  // (x0 / x1 hold the first batches of the samples at `first` / `second`)
+        if (first < n_act) {  // (x0 / x1 hold the stream's first two batches)
+            // Behind the static positions: a queue of ONE claimed position whose sample is being read from act[] (pos_q,
+            // s_q) and ONE claim in flight (ticket_q).  Within a refill the queue's requests go out BEFORE the column
+            // loads, so that the next step's wait for them (vmcnt is in order) leaves the other buffer's 8 KiB in flight.
             const bool dyn = use_claims && n_act > dyn0;  // (else every position is somebody's static one: no claims at all)
-            // the first ticket was taken ahead of the record (below); without one (first iteration of the launch) now
-            unsigned ticket = !dyn ? 0u : have_spec ? spec_ticket : take_ticket(my_claim);
-            bool spec_round = dyn && have_spec;  // ... and so was its sample read from act[]
-            if (second < n_act) {
-                unsigned acc = 0;
-                const v4u *p1 = UTM_COL_PTR(s_second);
-#pragma unroll 1
-                for (int j0 = 0; j0 < nsteps; j0 += U) {
-                    if (j0) { UTM_BATCH_LOAD(x1, p1, j0) }
-                    UTM_BATCH_COUNT(x1, j0)
+            unsigned pos_q = none, s_q = 0, ticket_q = 0;
+            bool ticket_out = false;
+            if (dyn) {
+                // the first TWO tickets were taken ahead of the record (below) and the first one's sample read: the queue
+                // starts full, and nothing that was requested a moment ago is waited for on the way from the record to
+                // the first new column loads.  Without them (first iteration of the launch) the same, now.
+                if (!have_spec) {
+                    spec_ticket = take_ticket(my_claim);
+                    spec_ticket2 = take_ticket(my_claim);
+                    spec2_out = true;
                 }
-                UTM_PARTIAL(second, acc, false)
+                pos_q = dyn0 + (unsigned)UTM_LOOP_WAVES * UTM_UNIFORM(spec_ticket) + (unsigned)wave;
+                if (pos_q < n_act) {
+                    s_q = have_spec ? (pos_q == patch_pos ? patch_s : spec_s) : UTM_ACT_LOAD(pos_q);
+                    if (spec2_out) {
+                        ticket_q = spec_ticket2;
+                    } else {
+                        ticket_q = take_ticket(my_claim);
+                    }
+                    ticket_out = true;
+                }
+                // (a second ticket behind a first one that came back out of range is simply dropped: both have returned --
+                // UTM_UNIFORM above and below -- before this wave's partial counts of the iteration go out)
+                else if (spec2_out) (void)UTM_UNIFORM(spec_ticket2);
+            } else if (!use_claims) {  // (experiment switch: the positions behind the static two dealt statically too)
+                pos_q = first + dyn0;
+                if (pos_q < n_act) s_q = UTM_ACT_LOAD(pos_q);
             }
-            unsigned cur = first, s = s_first;
-            const v4u *p = UTM_COL_PTR(s);
+            bool second_pending = second < n_act;
+            // the issue iterator: position it_pos (sample it_s) has had its batches below it_j requested.  The next batch of
+            // the stream -> (POS, J, S): at a position's end the next position is taken THEN (not earlier: a claimed
+            // position held back by a busy wave is one an idle wave could be reading) -- `second` once, then the queue's
+            // head, whose successor is claimed, and its sample requested, on the spot.  POS = none: the stream has ended.
+            unsigned it_pos = first, it_s = s_first;
+            int it_j = 0;
+#define UTM_IT_NEXT(POS, J, S)                                                                                             \
+    {                                                                                                                      \
+        if (it_j == nb && it_pos != none) {                                                                                \
+            it_j = 0;                                                                                                      \
+            if (second_pending) {                                                                                          \
+                second_pending = false;                                                                                    \
+                it_pos = second;                                                                                           \
+                it_s = s_second;                                                                                           \
+            } else if (pos_q < n_act) {                                                                                    \
+                it_pos = pos_q;                                                                                            \
+                it_s = UTM_UNIFORM(s_q);                                                                                   \
+                if (dyn) {                                                                                                 \
+                    pos_q = ticket_out ? dyn0 + (unsigned)UTM_LOOP_WAVES * UTM_UNIFORM(ticket_q) + (unsigned)wave : none;  \
+                    ticket_out = false;                                                                                    \
+                    if (pos_q < n_act) {                                                                                   \
+                        s_q = UTM_ACT_LOAD(pos_q);                                                                         \
+                        ticket_q = take_ticket(my_claim); /* (none is taken behind one that came back out of range) */    \
+                        ticket_out = true;                                                                                 \
+                    }                                                                                                      \
+                } else {                                                                                                   \
+                    pos_q += stride;                                                                                       \
+                    if (pos_q < n_act) s_q = UTM_ACT_LOAD(pos_q);                                                          \
+                }                                                                                                          \
+            } else {                                                                                                       \
+                it_pos = none;                                                                                             \
+            }                                                                                                              \
+        }                                                                                                                  \
+        POS = it_pos;                                                                                                      \
+        J = it_j;                                                                                                          \
+        S = it_s;                                                                                                          \
+        ++it_j;                                                                                                            \
+    }
+            // what the two buffers hold: the stream's batches 0 and 1 (requested ahead of the record)
+            unsigned pos_a, pos_b, s_dummy;
+            int j_a, j_b;
+            UTM_IT_NEXT(pos_a, j_a, s_dummy)
+            UTM_IT_NEXT(pos_b, j_b, s_dummy)
+            (void)s_dummy;
+            unsigned acc = 0;
+            // one step: count buffer X (batch J of position POS; a position's last batch sends its partial count), then
+            // refill it with the stream's next batch (the queue's requests, if any, go out first)
+#define UTM_LOOP_STEP(X, POS, J)                                                                                           \
+    {                                                                                                                      \
+        UTM_BATCH_COUNT(X, J)                                                                                              \
+        if (J == nb - 1) {                                                                                                 \
+            const bool drop = drop_iter && k + 1 == drop_iter && blockIdx.x == 1 && wave == 0 && POS == first;             \
+            UTM_PARTIAL(POS, acc, drop)                                                                                    \
+            acc = 0;                                                                                                       \
+        }                                                                                                                  \
+        unsigned s_now;                                                                                                    \
+        UTM_IT_NEXT(POS, J, s_now)                                                                                         \
+        if (POS != none) { UTM_BATCH_LOAD(X, s_now, J) }                                                                   \
+    }
             for (;;) {
-                // the claim was issued ahead of the column loads in flight, so it is back before them
-                // (use_claims == 0, an experiment switch: the positions behind the static two are dealt statically too)
-                const unsigned pos_n = dyn          ? dyn0 + (unsigned)UTM_LOOP_WAVES * UTM_UNIFORM(ticket) + (unsigned)wave
-                                       : use_claims ? 0xFFFFFFFFu
-                                                    : (cur == first ? first + dyn0 : cur + stride);
-                unsigned s_n = 0;  // (lands right behind the column loads: not waited for here)
-                if (pos_n < n_act) s_n = spec_round ? (pos_n == patch_pos ? patch_s : spec_s) : UTM_ACT_LOAD(pos_n);
-                spec_round = false;
-                unsigned acc = 0;
-#pragma unroll 1
-                for (int j0 = 0; j0 < nsteps; j0 += U) {
-                    if (j0) { UTM_BATCH_LOAD(x0, p, j0) }
-                    UTM_BATCH_COUNT(x0, j0)
-                }
-                const bool drop = drop_iter && k + 1 == drop_iter && blockIdx.x == 1 && wave == 0 && cur == first;
-                UTM_PARTIAL(cur, acc, drop)
+                if (pos_a == none && pos_b == none) break;
+                if (pos_a != none) {
+                    UTM_LOOP_STEP(x0, pos_a, j_a)
 #ifdef UTM_DEBUG_STAMPS
-                if (lane == 0 && k > 0 && cur == first && blockIdx.x == 1 && wave == 0) UTM_LSTAMP(sync, k - 1, 6);
+                    if (lane == 0 && k > 0 && blockIdx.x == 1 && wave == 0 && sync->stamps[(k - 1) & 255][6] == 0) UTM_LSTAMP(sync, k - 1, 6);
 #endif
-                if (pos_n >= n_act) break;  // (the one claim that came back out of range; none was issued behind it)
-                cur = pos_n;
-                s = UTM_UNIFORM(s_n);
-                if (dyn) ticket = take_ticket(my_claim);  // the next claim first, the loads behind it
-                p = UTM_COL_PTR(s);
-                UTM_BATCH_LOAD(x0, p, 0)
+                }
+                if (pos_b != none) { UTM_LOOP_STEP(x1, pos_b, j_b) }
             }
+#undef UTM_LOOP_STEP
+#undef UTM_IT_NEXT
+            // (ticket_out is false here: the last claim taken came back out of range and was waited for above -- every
+            // claim of this wave has returned before its last partial count went out)
         }
 #ifdef UTM_DEBUG_STAMPS
         if (lane == 0 && k == UTM_STAMP_ITER && blockIdx.x * UTM_LOOP_WAVES + wave < 8192) sync->wave_t[1][blockIdx.x * UTM_LOOP_WAVES + wave] = (u64)wall_clock64();
         if (blockIdx.x == 1 && threadIdx.x == 0) UTM_LSTAMP(sync, k, 2);
 #endif
-        // Ahead of the record: the first batches of the next iteration's two static positions.  Their samples stay where
-        // they are unless the record names one of those very positions (then it is loaded again below); a position that
-        // drops out of range costs one wasted batch.  These 16 KiB per wave are what keeps the memory pipes busy while
-        // the picker reduces, publishes, and the tile is brought up to date.
-        // The first batch goes out at once (it fills the tail of the iteration, while the slowest waves finish); the
-        // second is held back until `ahead` before the record is due -- iterations shrink smoothly, so the last interval
-        // between two records predicts this one -- so that it is still in flight when the record arrives.
+        // Ahead of the record: the first two batches of the next iteration's stream.  Their samples stay where they are
+        // unless the record names one of those very positions (then they are loaded again below); a position that drops
+        // out of range costs one wasted batch.  These 16 KiB per wave are what keeps the memory pipes busy while the
+        // picker reduces, publishes, and the tile is brought up to date.
         // ... and ahead of everything: this wave's first ticket of the next iteration and that position's sample (both
         // round trips are then off the path from the record to the first new column loads)
         have_spec = use_claims && n_act > dyn0 + 1;
+        spec2_out = false;
         if (have_spec) {
             unsigned *next_claim = claim + ((size_t)(((k + 1) % 3) * n_tiles + tile) * UTM_LOOP_WAVES + wave) * UTM_CLAIM_STRIDE;
             spec_ticket = take_ticket(next_claim);
             const unsigned pos_spec = dyn0 + (unsigned)UTM_LOOP_WAVES * UTM_UNIFORM(spec_ticket) + (unsigned)wave;
             spec_s = pos_spec < act_cap ? UTM_ACT_LOAD(pos_spec) : 0u;
+            if (pos_spec + 1 < n_act) {  // (in range whatever the record says: a second ticket, in flight until the iteration starts)
+                spec_ticket2 = take_ticket(next_claim);
+                spec2_out = true;
+            }
         }
+        // The first batch goes out at once (it fills the tail of the iteration, while the slowest waves finish); the
+        // second is held back until `ahead` before the record is due -- iterations shrink smoothly, so the last interval
+        // between two records predicts this one -- so that it is still in flight when the record arrives.
         const u64 t_due0 = (ahead0_ticks && t_iter) ? t_rec + t_iter - (t_iter > (u64)ahead0_ticks ? (u64)ahead0_ticks : t_iter) : 0;
         if (t_due0)
             while ((u64)wall_clock64() < t_due0) __builtin_amdgcn_s_sleep(2);  // (experiment: the first batch held back too)
-        if (first < n_act) { UTM_BATCH_LOAD(x0, UTM_COL_PTR(s_first), 0) }
+        UTM_AHEAD0()
         const u64 t_due = (ahead_ticks && t_iter) ? t_rec + t_iter - (t_iter > (u64)ahead_ticks ? (u64)ahead_ticks : t_iter) : 0;
         bool second_out = false;
-        if (second >= n_act) second_out = true;
-        else if (!t_due || (u64)wall_clock64() >= t_due) {
-            UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0)
+        if (!t_due || (u64)wall_clock64() >= t_due) {
+            UTM_AHEAD1()
             second_out = true;
         }
 
@@ -509,7 +578,7 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
                 r = loop_read_record(sync, epoch);
                 if (r.ok) break;
                 if (!second_out && (u64)wall_clock64() >= t_due) {
-                    UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0)
+                    UTM_AHEAD1()
                     second_out = true;
                 }
                 __builtin_amdgcn_s_sleep(4);
@@ -528,7 +597,7 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
             while (__hip_atomic_load(&rec_epoch_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != epoch && (u64)wall_clock64() < t_due)
                 __builtin_amdgcn_s_sleep(2);
         }
-        if (!second_out) { UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0) }
+        if (!second_out) { UTM_AHEAD1() }
         __syncthreads();
         const LoopRec r = rec_lds;
         if (r.stop) break;  // (uniform) the launch ends here: the winner stays pending, exactly as after a k_score_int launch
@@ -543,11 +612,12 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
             patch_s = r.moved;
             if (first == r.best_pos) {
                 s_first = r.moved;
-                if (first < n_act) { UTM_BATCH_LOAD(x0, UTM_COL_PTR(s_first), 0) }
+                UTM_AHEAD0()
+                if (nb > 1) { UTM_AHEAD1() }
             }
             if (second == r.best_pos) {
                 s_second = r.moved;
-                if (second < n_act) { UTM_BATCH_LOAD(x1, UTM_COL_PTR(s_second), 0) }
+                if (nb == 1) { UTM_AHEAD1() }
             }
         }
         __syncthreads();  // the tile is whole again (and rec_lds may be rewritten)
@@ -566,8 +636,9 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS) void k_loop_int(const u64 *__rest
         v4u *cv = reinterpret_cast<v4u *>(covered + w0);
         for (int k = threadIdx.x; k < nsteps * 64; k += UTM_LOOP_THREADS) cv[k] = ~live[k];
     }
+#undef UTM_AHEAD0
+#undef UTM_AHEAD1
 #undef UTM_PARTIAL
-#undef UTM_COL_PTR
 #undef UTM_UNIFORM
 #undef UTM_ACT_LOAD
 #undef UTM_COL_LOAD

@@ -126,7 +126,7 @@ struct Tune {
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
-    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, test_drop_arrival;   // persistent loop kernel
+    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, test_drop_arrival;   // persistent loop kernel
 };
 struct KnobDef {
     const char *name;
@@ -159,8 +159,11 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_P2P_REPLICATE", p2p_replicate, 1),
     UTM_KNOB_I("UTM_TEST_REMOTE_WINNER", test_remote_winner, 0),
     UTM_KNOB_I("UTM_PERSISTENT", persistent, 1),
-    UTM_KNOB_I("UTM_PERSIST_MAX_MB", persist_max_mb, 0),
+    UTM_KNOB_I("UTM_PERSIST_MAX_MB", persist_max_mb, 1200),  // (measured crossover at 2,504 samples: +2 % at 0.94 GB, -2.6 % at 1.56 GB)
     UTM_KNOB_I("UTM_PERSIST_WGS_PER_CU", persist_wgs_per_cu, 0),
+    UTM_KNOB_I("UTM_PERSIST_MAX_TILES", persist_max_tiles, 32),
+    UTM_KNOB_I("UTM_PERSIST_TILE_KIB", persist_tile_kib, 0),
+    UTM_KNOB_I("UTM_PERSIST_MAX_SAMPLES", persist_max_samples, 2560),  // (one chunk of count words for the picker: UTM_LOOP_THREADS x UTM_LOOP_E)
     UTM_KNOB_I("UTM_PERSIST_CLAIMS", persist_claims, 1),
     UTM_KNOB_I("UTM_PERSIST_AHEAD0_TICKS", persist_ahead0_ticks, 0),
     UTM_KNOB_I("UTM_PERSIST_AHEAD_TICKS", persist_ahead_ticks, 400),  // 10 ns ticks: the second run-ahead batch goes out this long before the record is due (0: at once)
