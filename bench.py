@@ -156,8 +156,11 @@ def roofline_pass(m, k_sel, af, rank=0):
     achieved = ps["algo_bytes"] / (ps["score_ms"] * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": None,
-            "kernel": "k_score_afs (+ k_score_afq for the first launches)" if af else "k_score_int (pick fused in on one GPU)",
-            "launches": ps["score_launches"], "avg_launch_us": ps["score_ms"] * 1e3 / max(1, ps["score_launches"]),
+            "kernel": ("k_score_afs (+ k_score_afq for the first launches)" if af else
+                       "k_loop_int (persistent: up to 256 iterations per launch, pick inside)" if ps["persist_iterations"] else
+                       "k_score_int (pick fused in on one GPU)"),
+            "launches": ps["score_launches"], "iterations_in_persistent_launches": ps["persist_iterations"],
+            "avg_launch_us": ps["score_ms"] * 1e3 / max(1, ps["score_launches"]),
             "algo_bytes_per_launch": ps["algo_bytes"] / max(1, ps["score_launches"]), "rank": rank}
 
 
@@ -194,7 +197,7 @@ def live_pmc_traffic(spec, extra):
                 return None
             with open(max(files, key=os.path.getmtime)) as fh:
                 per_launch[counter] = [float(r["Counter_Value"]) for r in csv.DictReader(fh)
-                                       if "k_score_" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+                                       if ("k_score_" in r["Kernel_Name"] or "k_loop_int" in r["Kernel_Name"]) and r["Counter_Name"] == counter]
         except (OSError, subprocess.SubprocessError, KeyError, ValueError):
             return None
         finally:
@@ -303,7 +306,7 @@ def summarize(spec, label, world, steps, res, roofline, t_gen):
             "generator_s": round(t_gen, 3),
             **({k: st[k] for k in ("af_chained_iterations", "af_deferred_rows")} if spec["af"] else {}),  # (of the last step)
             "roofline": None if roofline is None else {k: roofline[k] for k in ("frac", "achieved", "kernel", "launches", "avg_launch_us",
-                                                                               "algo_bytes_per_launch")}}
+                                                                               "algo_bytes_per_launch", "iterations_in_persistent_launches")}}
 
 
 def workload_label(spec):
