@@ -67,6 +67,8 @@ def parse():
     p.add_argument("--cpu-budget-s", type=float, default=75.0,
                    help="CPU seconds the reference port may take; one iteration at full N is timed when it fits here and in host RAM")
     p.add_argument("--no-roofline-pass", action="store_true")
+    p.add_argument("--no-calibration", action="store_true", help="N = 1: skip the streaming-read calibration leg")
+    p.add_argument("--calibration-launches", type=int, default=20)
     p.add_argument("--no-also", action="store_true", help="N = 1: skip the other BASELINE configurations after the headline")
     p.add_argument("--af-estimate-scores", action="store_true",
                    help="AF: do not chain unambiguous winners (same rows; reported scores are estimates)")
@@ -179,7 +181,7 @@ def live_pmc_traffic(spec, extra):
         return None
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None      # this process is itself being profiled: no nested profiler runs
-    work = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-pass", "--no-also", "--pmc-traffic", "off",
+    work = ["--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline-pass", "--no-also", "--no-calibration", "--pmc-traffic", "off",
             "--n-var", str(spec["n_var"]), "--n-samp", str(spec["n_samp"]), "--select", str(spec["select"]),
             "--seed", str(spec["seed"]), "--chunk-vars", str(spec["chunk_vars"])] + extra
     if spec["af"]:
@@ -303,10 +305,12 @@ def summarize(spec, label, world, steps, res, roofline, t_gen):
             "iterations_per_step": res["iters"] // max(1, steps), "tot_captured": st["tot_captured"], "chunks": st["n_chunks"],
             "algo_bytes_per_step": st["algo_bytes"] * world, "hbm_gbps_whole_loop": gbps,
             "hbm_frac_whole_loop": gbps / (HBM_PEAK_GBPS * world), "device_loop_ms_per_step": res["loop_ms"] / max(1, steps),
+            **({"whole_loop_frac_of_stream": gbps / roofline["stream_calibration_gbps"]} if roofline and roofline.get("stream_calibration_gbps") else {}),
             "generator_s": round(t_gen, 3),
             **({k: st[k] for k in ("af_chained_iterations", "af_deferred_rows")} if spec["af"] else {}),  # (of the last step)
-            "roofline": None if roofline is None else {k: roofline[k] for k in ("frac", "achieved", "kernel", "launches", "avg_launch_us",
-                                                                               "algo_bytes_per_launch", "iterations_in_persistent_launches")}}
+            "roofline": None if roofline is None else {k: roofline.get(k) for k in ("frac", "achieved", "kernel", "launches", "avg_launch_us",
+                                                                                   "algo_bytes_per_launch", "iterations_in_persistent_launches",
+                                                                                   "stream_calibration_gbps", "frac_of_stream")}}
 
 
 def workload_label(spec):
@@ -337,6 +341,7 @@ def headline_line(args, world, n_total, exchange, exchange_note, final_stats, st
         "decremental_interleaved_copy_bytes": st["decr_interleaved_bytes"] if args.decremental else 0,
         "brute_force_equivalent_gbps": st["brute_force_bytes"] * world * args.steps / res["elapsed"] / 1e9,
         "hbm_gbps_whole_loop": head["hbm_gbps_whole_loop"], "hbm_frac_whole_loop": head["hbm_frac_whole_loop"],
+        "whole_loop_frac_of_stream": head.get("whole_loop_frac_of_stream"),
         "device_loop_ms_per_step": head["device_loop_ms_per_step"],
         "sharded_rows_match_single_gpu": None,
         # UTM_* knobs set in this process's environment (launch shapes / thresholds / test hooks, never results): a
@@ -402,6 +407,12 @@ def main():
             return value
         return max(r[0] for r in transport.allgather((float(value), 0, 0)))
 
+    # N = 1: what this box streams today -- plain read-only passes over the resident matrix with the scoring kernel's access
+    # shape, timed in this process right before the headline (boxes differ by a few percent; the spec peak does not say)
+    calibration_gbps = None
+    if world == 1 and not args.no_calibration:
+        calibration_gbps = m.stream_calibration(max(20, args.calibration_launches))
+
     exchange_note = None
     try:
         res = timed_steps(m, k_sel, args.steps, args.warmup, sync_max)
@@ -434,6 +445,11 @@ def main():
     roofline = None
     if not args.no_roofline_pass and not args.decremental:   # the roofline object describes the brute-force kernel only
         roofline = roofline_pass(m, k_sel, args.af, rank)
+        if roofline is not None and calibration_gbps:
+            roofline["stream_calibration_gbps"] = calibration_gbps
+            roofline["frac_of_stream"] = roofline["achieved"] / calibration_gbps
+            roofline["stream_calibration"] = ("k_stream_read: read-only, 16 B per lane non-temporal, 1 KiB per wave instruction, 8 in flight, "
+                                              f"{max(20, args.calibration_launches)} passes over the resident matrix in this process before the headline")
 
     # N > 1: the same steps again through north_star's RCCL protocol, measured beside the default exchange.  These legs
     # bring up a communicator that the headline did not need: should that, or a collective, hang on some node, every
@@ -539,8 +555,12 @@ def main():
                 m2, t2 = build_matrix(device, s2, dev_index)
                 with m2:
                     k2 = select_count(s2)
+                    cal2 = m2.stream_calibration(20 if s2["n_var"] * s2["n_samp"] < 4e11 else 3)
                     r2 = timed_steps(m2, k2, 1, 1 if name in ("cfg1", "cfg3", "af64") else 0, lambda v: v)
                     roof2 = roofline_pass(m2, k2, s2["af"])
+                    if roof2 is not None:
+                        roof2["stream_calibration_gbps"] = cal2
+                        roof2["frac_of_stream"] = roof2["achieved"] / cal2
                 also[name] = summarize(s2, WORKLOADS[name][0], 1, 1, r2, roof2, t2)
             except device.nat.NativeError as exc:      # e.g. a GPU with less HBM than the 156 GB of cfg5
                 also[name] = {"workload": WORKLOADS[name][0], "error": str(exc)}

@@ -68,7 +68,7 @@ extern "C" {
 #define UTM_ECOMM (-5)    /* RCCL error / RCCL not available */
 
 #define UTM_ABI_VERSION 3 /* 2: utm_stats.exchange / rccl_ranks; host-memory mailbox and replica entry points removed
-                           * 3: utm_env_overrides; utm_stats.persist_launches / persist_iterations */
+                           * 3: utm_env_overrides; utm_stats.persist_launches / persist_iterations; utm_stream_calibration */
 
 typedef struct utm_ctx utm_ctx;
 
@@ -203,6 +203,11 @@ int utm_set_decremental(utm_ctx *ctx, int32_t on, double threshold);
  * writes the reference's TSV columns needs.  Ambiguous iterations (ties within the error bound) are always chained,
  * and so is everything on a context that holds only a shard of the samples (its records meet other shards'). */
 int utm_set_af_exact_scores(utm_ctx *ctx, int32_t on);
+/* Streaming-read calibration: `launches` plain read-only passes over the context's resident columns with the scoring
+ * kernel's access shape (16 B per lane non-temporal loads, 1 KiB per wave instruction, 8 in flight, ~32k workgroups) and
+ * nothing else -- *gbps_out = bytes read / stream time.  What the box delivers today, beside the 8 TB/s spec peak: the bench
+ * reports it as roofline.stream_calibration_gbps so that box-to-box variance can be told from kernel quality. */
+int utm_stream_calibration(utm_ctx *ctx, int32_t launches, double *gbps_out);
 /* Switch per-launch HIP-event timing of the scoring kernels on/off (same as UTM_FLAG_PROFILE_EVENTS). */
 int utm_set_profile(utm_ctx *ctx, int32_t on);
 

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "utm_get_covered": [_P, _I32, _P],
     "utm_get_stats": [_P, ctypes.POINTER(Stats)],
     "utm_set_profile": [_P, _I32],
+    "utm_stream_calibration": [_P, _I32, ctypes.POINTER(ctypes.c_double)],
     "utm_set_af_exact_scores": [_P, _I32],
     "utm_set_decremental": [_P, _I32, ctypes.c_double],
     "utm_local_best": [_P, ctypes.POINTER(Record)],

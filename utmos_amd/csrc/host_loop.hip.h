@@ -786,6 +786,36 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     return UTM_OK;
 }
 
+// What this GPU streams right now: `launches` plain read-only passes over the resident columns of every chunk, timed with
+// the loop's own events on the context's stream.  The scoring kernels cannot go faster than this on this box today.
+extern "C" int utm_stream_calibration(utm_ctx *c, int32_t launches, double *gbps_out)
+{
+    CTX(c);
+    if (!gbps_out || launches < 1) return fail(UTM_EINVAL, "bad arguments");
+    if (c->chunks.empty()) return fail(UTM_ESTATE, "no chunks");
+    Scratch<u64> sink;
+    HIP_TRY(sink.alloc(1));
+    u64 bytes = 0;
+    auto pass = [&]() {
+        for (auto &ch : c->chunks) {
+            const u64 n_kib = (u64)c->n_local * ch.wp * 8 / 1024;
+            const unsigned grid = (unsigned)std::min<u64>(32768, std::max<u64>(1, (n_kib + 127) / 128));
+            hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, c->stream, (const u64 *)ch.cols, n_kib, sink.p);
+        }
+    };
+    pass();  // (warm-up: code object, page tables)
+    HIP_TRY(hipEventRecord(c->ev_loop0, c->stream));
+    for (int i = 0; i < launches; ++i) pass();
+    HIP_TRY(hipEventRecord(c->ev_loop1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_loop1));
+    HIP_TRY(hipGetLastError());
+    for (auto &ch : c->chunks) bytes += (u64)c->n_local * ch.wp * 8;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_loop0, c->ev_loop1));
+    *gbps_out = ms > 0 ? (double)bytes * launches / (ms * 1e-3) / 1e9 : 0.0;
+    return UTM_OK;
+}
+
 extern "C" int utm_set_decremental(utm_ctx *c, int32_t on, double threshold)
 {
     CTX(c);

@@ -66,6 +66,34 @@ __global__ __launch_bounds__(256) void k_col_popcount(const u64 *__restrict__ co
     if (threadIdx.x == 0) out[s] += part[0] + part[1] + part[2] + part[3];
 }
 
+// Streaming-read calibration (utm_stream_calibration): what this GPU delivers, here and now, to the scoring kernel's access
+// shape with nothing else attached -- 16 B per lane non-temporal loads, 1 KiB per wave instruction, 8 in flight per wave,
+// 32 KiB per wave per workgroup step, a grid of ~32k workgroups of 256 threads over the resident columns.  No LDS tile, no
+// reduction tree, no atomics: one XOR per load and one (never taken) store per wave keep the loads alive.
+__global__ __launch_bounds__(256) void k_stream_read(const u64 *__restrict__ cols, u64 n_kib, u64 *__restrict__ sink)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const v4u *base = reinterpret_cast<const v4u *>(cols) + lane;
+    v4u acc = {0, 0, 0, 0};
+    // wave w of block b reads the 32 KiB pieces b*4+w, b*4+w + 4*gridDim.x, ... (whole KiB: 64 lanes x 16 B)
+    for (u64 piece = (u64)blockIdx.x * 4 + wave; piece * 32 < n_kib; piece += (u64)gridDim.x * 4) {
+        const u64 k0 = piece * 32;
+        const u64 left = n_kib - k0;
+#pragma unroll 1
+        for (int j0 = 0; j0 < 32 && (u64)j0 < left; j0 += 8) {
+            v4u x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const u64 kib = k0 + j0 + u;
+                x[u] = __builtin_nontemporal_load(base + (kib < n_kib ? kib : n_kib - 1) * 64);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= x[u];
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u && lane == 63) sink[0] = acc.x;  // (practically never: keeps the loads)
+}
+
 // Synthetic chunk contents: thread = one word (64 variants) of one local sample.  Grid = (word blocks,
 // min(samples, 65535)); the samples are strided over grid.y -- a 1-D grid of words x samples would exceed
 // HIP's 2^32 threads per grid dimension on large chunks and be silently truncated.

@@ -170,6 +170,12 @@ class DeviceMatrix:
         """AF modes: off = skip the sequential chain of an unambiguous winner (same rows; scores become estimates)."""
         nat.check(nat.lib().utm_set_af_exact_scores(self._h, 1 if on else 0))
 
+    def stream_calibration(self, launches=20):
+        """GB/s of plain streaming reads over the resident columns (the scoring kernel's access shape, nothing else)."""
+        out = ctypes.c_double(0.0)
+        nat.check(nat.lib().utm_stream_calibration(self._h, int(launches), ctypes.byref(out)))
+        return out.value
+
     def set_profile(self, on):
         nat.check(nat.lib().utm_set_profile(self._h, 1 if on else 0))
 
