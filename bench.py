@@ -88,6 +88,8 @@ def parse():
                    help="a BASELINE.json configuration by name (sets the shape flags): " +
                         "; ".join(f"{k}: {v[0]}" for k, v in sorted(WORKLOADS.items())))
     p.add_argument("--force-comm", action="store_true", help="initialise RCCL even with one rank (exercises the RCCL exchange)")
+    p.add_argument("--force-mailboxes", action="store_true",
+                   help="one rank: exchange through the device mailboxes anyway (the shard posts to and collects from itself)")
     args = p.parse_args()
     args.explicit_shape = bool(args.workload) or any(a.startswith(("--n-var", "--n-samp", "--select", "--af", "--chunk-vars",
                                                                    "--decremental", "--seed")) for a in sys.argv[1:])
@@ -394,6 +396,14 @@ def main():
             exchange = connect_shards(m, transport, uid, "auto" if args.exchange == "both" else args.exchange)
         except RuntimeError as err:
             raise SystemExit(f"bench.py rank {rank}: {err}")
+    elif args.force_mailboxes:
+        # the ONE shard exports to and imports from itself, passes the self-test and posts its record to its own mailbox every
+        # iteration: the device-side exchange's per-iteration cost without a second GPU
+        m.p2p_import(0, [m.p2p_export()])
+        if not m.p2p_selftest():
+            raise SystemExit("bench.py: the mailbox self-test failed on this device")
+        m.p2p_use_mailboxes("single")
+        exchange = "mailboxes"
     elif args.force_comm:
         m.comm_init(0, 1, device.DeviceMatrix.comm_unique_id())
         exchange = "rccl"
@@ -527,7 +537,7 @@ def main():
     # N > 1: rank 0 re-runs the whole problem alone (untimed, own context) and compares the rows -- evidence
     # from this very run that the sharded exchange decides exactly like a single GPU
     sharded_check = None
-    if (world > 1 or args.force_comm) and rank == 0 and not args.no_sharded_check:
+    if (world > 1 or args.force_comm or args.force_mailboxes) and rank == 0 and not args.no_sharded_check:
         solo, _ = build_matrix(device, spec, dev_index)
         with solo:
             s_idx, s_new, _ = solo.run(k_sel)
@@ -546,7 +556,7 @@ def main():
 
     # N = 1, default workload: the other single-GPU BASELINE configurations, one step each
     also = None
-    if world == 1 and not args.explicit_shape and not args.no_also and not args.force_comm:
+    if world == 1 and not args.explicit_shape and not args.no_also and not args.force_comm and not args.force_mailboxes:
         also = {}
         for name in ALSO:
             s2 = dict(af=False, af_dtype="f32", chunk_vars=0, seed=args.seed)

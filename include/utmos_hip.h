@@ -48,6 +48,8 @@
  *   UTM_PERSISTENT (1)        integer scores, one chunk, the only shard: a batch of iterations as ONE persistent launch
  *                             (workers keep their covered tile in LDS, the picker's record replaces the kernel boundary)
  *   UTM_PERSIST_MAX_MB (0 = no limit) largest matrix run that way; UTM_PERSIST_WGS_PER_CU (0 = what the occupancy query allows)
+ *   UTM_MBOX_SPINS_LOG2 (24)  mailbox exchange: polls (x ~0.5 us) before a peer's record is declared lost (UTM_ECOMM)
+ *   UTM_TEST_MUTE_EXCHANGE (0) test hook: in that iteration since the reset this shard posts no record into the mailboxes
  *   UTM_TEST_DROP_ARRIVAL (0) test hook: in that scoring launch / persistent iteration since the reset one partial count is
  *                             withheld, so that the pick's bounded wait runs out (UTM_EHIP; the context works again after utm_reset)
  */
@@ -237,6 +239,9 @@ int utm_p2p_import(utm_ctx *ctx, int32_t rank, int32_t n_ranks, const void *blob
  * every peer's test record.  If ALL shards report 1, call utm_p2p_use_mailboxes(ctx, 1) on every shard; utm_run
  * is then collective over the shards exactly like after utm_comm_init. */
 int utm_p2p_selftest(utm_ctx *ctx, int32_t *ok);
+/* on = 1: as above.  on = 2: also on a context that is the ONLY shard (exported to and imported from itself): it then posts
+ * to and collects from its own mailbox every iteration -- the exchange's own per-iteration cost, measurable on one GPU
+ * (bench.py --force-mailboxes).  on = 0: off. */
 int utm_p2p_use_mailboxes(utm_ctx *ctx, int32_t on);
 /* ---- RCCL (one process per GPU; ids are exchanged by the caller) ------------------------------ */
 #define UTM_UNIQUE_ID_BYTES 128

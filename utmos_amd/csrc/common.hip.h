@@ -123,6 +123,8 @@ struct PickArgs {
     int early_pick;      // the only shard: k_cand also makes the pick when no chain is needed (the chain launches behind it
                          // then return at once; when one is needed, their last workgroup picks)
     Rec *recs;       // every shard's record of the current iteration, recs[rank]
+    unsigned mbox_spins;     // polls of a mailbox slot before a peer's record is declared lost (x s_sleep(16))
+    int test_mute;           // test hook (UTM_TEST_MUTE_EXCHANGE): in that iteration this shard posts no record (a peer that went away)
     int test_drop;           // test hook (UTM_TEST_DROP_ARRIVAL): this launch withholds one partial count, so that the pick's bounded wait runs out
     int remote_winner_test;  // test hook: treat a local winner's column as remote too (it is then read from the
                              // winner-column buffer the exchange filled), so that one rank can exercise that path

@@ -433,12 +433,12 @@ static int enqueue_pick_and_exchange(utm_ctx *c, bool decr = false)
     const unsigned pick_threads = pick_env ? (unsigned)pick_env : c->active_ub > 16384 ? 1024 : 512;
     PickArgs a = pick_args(c, decr);
     const int chain_pick = c->tune.chain_pick;
-    const bool only_shard = c->n_ranks == 1 && c->n_local == c->n_total && !c->comm;
+    const bool only_shard = c->n_ranks == 1 && c->n_local == c->n_total && !c->comm && !mailbox_exchange(c);
     if (enqueue_candidates(c, a, /*pick_inside=*/only_shard && chain_pick)) {
         HIP_TRY(hipGetLastError());
         return UTM_OK;  // the chain launch's last workgroup runs k_pick<0>'s body
     }
-    if (c->n_ranks > 1 && c->mbox_ok) {
+    if (mailbox_exchange(c)) {
         // device-side exchange: post this shard's record into every shard's mailbox, wait for theirs, decide
         hipLaunchKernelGGL(k_pick<2>, dim3(1), dim3(1024), 0, c->stream, a);  // pick, post, collect, decide
     } else if (c->comm) {
@@ -582,7 +582,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         if (defer) c->defer_lo = std::max(c->defer_lo, first_is_full ? c->iter : c->iter - 1);
         const i64 swaps0 = c->cov_swaps_enqueued;
         // where the pick runs: inside the scoring launch on the only shard (1) and on a shard of the mailbox exchange (2)
-        const int fuse_mode = (c->n_ranks > 1 && c->mbox_ok) ? 2 : (c->n_ranks == 1 && c->n_local == c->n_total && !c->comm) ? 1 : 0;
+        const int fuse_mode = mailbox_exchange(c) ? 2 : (c->n_ranks == 1 && c->n_local == c->n_total && !c->comm) ? 1 : 0;
         // short scans (and any matrix whose tile grid fits the resident blocks): the whole batch as ONE persistent launch
         const LoopShape loop = (!decr && fuse_mode == 1 && c->tune.fuse_pick) ? loop_shape(c) : LoopShape();
         if (loop.ok) TRY(enqueue_loop(c, loop, (int)n));
@@ -769,8 +769,8 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->decr_iterations = c->decr_iterations;
     out->brute_force_bytes = c->brute_bytes;
     out->p2p_replica_bytes = (i64)c->replica_bytes;
-    out->exchange = c->n_local == c->n_total && !c->comm ? UTM_EXCHANGE_NONE
-                    : (c->n_ranks > 1 && c->mbox_ok)     ? UTM_EXCHANGE_MAILBOX
+    out->exchange = mailbox_exchange(c)                        ? UTM_EXCHANGE_MAILBOX
+                    : c->n_local == c->n_total && !c->comm ? UTM_EXCHANGE_NONE
                     : c->comm                            ? (c->column_by_allreduce ? UTM_EXCHANGE_RCCL_SUM : UTM_EXCHANGE_RCCL)
                                                          : UTM_EXCHANGE_CALLER;
     out->af_chained_iterations = c->prepared ? (i64)c->h_st->chain_events : 0;

@@ -254,6 +254,8 @@ static PickArgs pick_args(utm_ctx *c, bool decr = false)
     a.known_val = c->d_known_val;
     a.recs = reinterpret_cast<Rec *>(c->d_xbuf);
     a.remote_winner_test = c->remote_winner_test ? 1 : 0;
+    a.mbox_spins = 1u << std::min(28, std::max(4, c->tune.mbox_spins_log2));
+    a.test_mute = c->tune.test_mute_exchange;
     a.test_drop = (c->tune.test_drop_arrival > 0 && c->score_launches == c->tune.test_drop_arrival) ? 1 : 0;  // (the launch being enqueued)
     a.res_idx = c->d_res_idx;
     a.res_new = c->d_res_new;

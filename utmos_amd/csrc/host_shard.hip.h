@@ -210,6 +210,7 @@ extern "C" int utm_p2p_import(utm_ctx *c, int32_t rank, int32_t n_ranks, const v
             if (r != rank) need += (u64)locals[r] * c->col_words * 8;
         size_t free_b = 0, total_b = 0;
         const bool wanted = n_ranks > 1 && c->tune.p2p_replicate != 0;
+        if (n_ranks == 1 && c->tune.p2p_replicate != 0) c->replicated = true;  // (no peers: every column is local already)
         if (wanted && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (u64)free_b > need + (8ull << 30)) {
             // allocate everything first: a refusal (another process took the room meanwhile) just keeps the in-place reads
             bool room = true;
@@ -295,6 +296,7 @@ extern "C" int utm_p2p_use_mailboxes(utm_ctx *c, int32_t on)
     CTX(c);
     if (on && (!c->p2p || !c->d_peer_mbox)) return fail(UTM_ESTATE, "mailboxes are not mapped");
     c->mbox_ok = on != 0;
+    c->mbox_single = on == 2;  // (a single shard posts to and collects from itself: what the exchange costs, on one GPU)
     c->prepared = false;
     return UTM_OK;
 }

@@ -100,10 +100,10 @@ __device__ __forceinline__ void decide_single(const PickArgs &a, const Cand &bes
 
 // Device-side exchange, receiving end: wait (bounded) until every shard's record of this exchange has
 // landed in the local mailbox, copy them into the record slots, decide.  One lane per source shard.
-#define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost
-__device__ __forceinline__ bool mbox_wait(const Mailbox *slot, u64 expected, Rec *out)
+#define UTM_MBOX_SPINS (1u << 24)  // x s_sleep(16): several seconds before a missing shard is declared lost (UTM_MBOX_SPINS_LOG2)
+__device__ __forceinline__ bool mbox_wait(const Mailbox *slot, u64 expected, Rec *out, unsigned spins = UTM_MBOX_SPINS)
 {
-    for (unsigned spin = 0; spin < UTM_MBOX_SPINS; ++spin) {
+    for (unsigned spin = 0; spin < spins; ++spin) {
         if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == expected) {
             out->score = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<const u64 *>(&slot->score), __ATOMIC_RELAXED,
                                                                       __HIP_MEMORY_SCOPE_SYSTEM));
@@ -128,14 +128,16 @@ __device__ __forceinline__ void mailbox_exchange_and_decide(const PickArgs &a, i
         const Rec mine = *rec_of(a, a.rank);
         const u64 seq = st->xseq + 1;
         Mailbox *dst = a.peer_mbox[threadIdx.x] + (seq & 1) * a.n_ranks + a.rank;
-        __hip_atomic_store(reinterpret_cast<u64 *>(&dst->score), __builtin_bit_cast(u64, mine.score), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(reinterpret_cast<u64 *>(&dst->idx), (u64)mine.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(reinterpret_cast<u64 *>(&dst->new_count), (u64)mine.new_count, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!(a.test_mute && st->iter + 1 == (i64)a.test_mute)) {  // (test hook: a shard that posts nothing)
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->score), __builtin_bit_cast(u64, mine.score), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->idx), (u64)mine.idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<u64 *>(&dst->new_count), (u64)mine.new_count, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&dst->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         const Mailbox *slot = a.mbox + (seq & 1) * a.n_ranks + threadIdx.x;
-        if (!mbox_wait(slot, seq, rec_of(a, threadIdx.x))) *late = 1;
+        if (!mbox_wait(slot, seq, rec_of(a, threadIdx.x), a.mbox_spins)) *late = 1;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -126,7 +126,8 @@ struct Tune {
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
-    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, test_drop_arrival;   // persistent loop kernel
+    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, test_drop_arrival;
+    int mbox_spins_log2, test_mute_exchange;                                 // mailbox exchange: patience, test hook   // persistent loop kernel
 };
 struct KnobDef {
     const char *name;
@@ -168,6 +169,8 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_PERSIST_AHEAD0_TICKS", persist_ahead0_ticks, 0),
     UTM_KNOB_I("UTM_PERSIST_AHEAD_TICKS", persist_ahead_ticks, 400),  // 10 ns ticks: the second run-ahead batch goes out this long before the record is due (0: at once)
     UTM_KNOB_I("UTM_TEST_DROP_ARRIVAL", test_drop_arrival, 0),
+    UTM_KNOB_I("UTM_MBOX_SPINS_LOG2", mbox_spins_log2, 24),
+    UTM_KNOB_I("UTM_TEST_MUTE_EXCHANGE", test_mute_exchange, 0),
 };
 static void read_tune(Tune *t)
 {
@@ -326,6 +329,7 @@ struct utm_ctx {
     std::vector<void *> mbox_opened;
     Mailbox *mbox_local = nullptr;       // the slots this shard polls (= d_mbox once the peers' mailboxes are mapped)
     bool mbox_ok = false;                // every shard passed the mailbox self-test: utm_run exchanges through them
+    bool mbox_single = false;            // ... even with ONE shard (utm_p2p_use_mailboxes(ctx, 2)): the exchange's own cost, measurable on one GPU
     u64 xseq_host = 0;                   // exchanges completed so far (self-test rounds included)
 
     // stats
@@ -345,7 +349,9 @@ static inline u64 round_up(u64 x, u64 m) { return (x + m - 1) / m * m; }
 // (every workgroup would pull the remote tile over xGMI): k_apply_pending reads the column once instead.
 // The per-iteration exchange runs through RCCL (records all-gathered, winner column broadcast) rather than through
 // the device mailboxes; a communicator next to working mailboxes is not used by the loop.
-static bool rccl_exchange(const utm_ctx *c) { return c->comm && !(c->n_ranks > 1 && c->mbox_ok); }
+// The device mailboxes carry the loop: mapped and self-tested on every shard (and more than one shard, unless forced).
+static bool mailbox_exchange(const utm_ctx *c) { return c->mbox_ok && (c->n_ranks > 1 || c->mbox_single); }
+static bool rccl_exchange(const utm_ctx *c) { return c->comm && !mailbox_exchange(c); }
 // ... in its broadcast form: the host has to learn the winner's rank after every iteration
 static bool rccl_needs_root(const utm_ctx *c) { return rccl_exchange(c) && !c->column_by_allreduce; }
 // Remote winners are read in place through the hipIpc mappings (not from a local copy / the broadcast buffer).

@@ -229,7 +229,7 @@ class DeviceMatrix:
 
     def p2p_use_mailboxes(self, on=True):
         """After every shard's self-test passed: run() becomes collective, records travel through the mailboxes."""
-        nat.check(nat.lib().utm_p2p_use_mailboxes(self._h, 1 if on else 0))
+        nat.check(nat.lib().utm_p2p_use_mailboxes(self._h, 2 if on == "single" else 1 if on else 0))
         self.fused_mailboxes = bool(on)
         self.fused = bool(on) or getattr(self, "has_comm", False)
 
