@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collect the round's evidence on a GPU box (run from the repo root through gpurun); writes gpurun_out/prof_<tag>/ and
 # condensed files under gpurun_out/profiles_r02/ (copy those into profiles/).
-#   tools/collect_profiles.sh r02
+#   tools/collect_profiles.sh r03
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/profiles_$tag
 mkdir -p $out
@@ -12,7 +12,7 @@ echo "== headline (unprofiled), default invocation"
 python3 $R/bench.py --steps 5 --warmup 2 > $out/${tag}_cfg2_bench.json 2> $out/${tag}_cfg2_bench.err || exit 1
 for cfg in cfg2 cfg3 cfg1; do
   extra="--workload $cfg"; [ $cfg = cfg2 ] && extra="--no-also"
-  prefix="void k_score_int"; [ $cfg = cfg3 ] && prefix="void k_score_afs,void k_score_afq"
+  prefix="void k_score_int"; [ $cfg = cfg3 ] && prefix="void k_score_afs,void k_score_afq"; [ $cfg = cfg1 ] && prefix="void k_loop_int"
   echo "== $cfg kernel trace + stats"
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_${cfg}_kt -- python3 $R/bench.py $extra --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_${cfg}_bench_under_rocprofv3.json 2> /dev/null || exit 1
   for counter in FETCH_SIZE WRITE_SIZE; do
@@ -23,6 +23,15 @@ for cfg in cfg2 cfg3 cfg1; do
   python3 $R/tools/trace_gaps.py $R/gpurun_out/prof_${tag}_${cfg}_kt > $out/${tag}_${cfg}_stream_time.txt 2>&1
   find $R/gpurun_out/prof_${tag}_${cfg}_kt $R/gpurun_out/prof_${tag}_${cfg}_FETCH_SIZE $R/gpurun_out/prof_${tag}_${cfg}_WRITE_SIZE -name "*.csv" -size +3M -delete
 done
+echo "== SQ / TCC counters of the integer scoring kernel (first 120 iterations of cfg2) and of the persistent loop (cfg1)"
+(cd $R && python3 tools/pmc_sq.py ${tag}_cfg2 k_score_int -- --steps 1 --warmup 0 --select 120 --no-cpu-baseline --no-roofline-pass --no-also --no-calibration --pmc-traffic off > /dev/null 2>&1)
+(cd $R && python3 tools/pmc_sq.py ${tag}_cfg1 k_loop_int -- --workload cfg1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline-pass --no-calibration --pmc-traffic off > /dev/null 2>&1)
+cp $R/profiles/${tag}_cfg2_pmc_sq.json $R/profiles/${tag}_cfg1_pmc_sq.json $out/ 2>/dev/null
+echo "== per-iteration cost of every exchange form, from one GPU (10M x 313 = one rank's share of cfg2 at 8 GPUs; cfg2)"
+(cd $R && AB_REPS="1 2" bash tools/exchange_table.sh "--n-var 10000000 --n-samp 313" > $out/${tag}_exchange_cost_one_gpu_shard_shape_10Mx313.txt 2>&1)
+(cd $R && AB_REPS=1 AB_STEPS=2 bash tools/exchange_table.sh "--n-var 10000000 --n-samp 2504" > $out/${tag}_exchange_cost_one_gpu_cfg2.txt 2>&1)
+echo "== persistent loop vs one launch per iteration over matrix heights (same box)"
+(cd $R && bash tools/ab_sizes.sh "100000 300000 600000 1103547 1500000 2000000 3000000 5000000" > $out/${tag}_persistent_vs_launches_by_height.txt 2>&1)
 echo "== float64 AF (the reference's in-memory --af values)"
 python3 $R/bench.py --af --af-dtype f64 --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_bench.json 2>/dev/null
 python3 $R/bench.py --workload af64 --af-estimate-scores --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_cli_mode_bench.json 2>/dev/null
