@@ -220,3 +220,35 @@ def test_a_shard_that_never_posts_ends_the_loop_with_ecomm_and_the_context_recov
         got = m.run(n_samp)
         assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
         assert m.exchange() == "mailboxes"
+
+
+def test_verification_stage_that_never_counts_in_ends_in_an_error_and_the_context_recovers(monkeypatch):
+    """ADVICE r2 (k_verify's stages wait on lower-indexed workgroups of the same launch; every wait is bounded): with
+    UTM_TEST_DROP_ARRIVAL one compaction workgroup of the first verification does not count in -- two identical best
+    columns force chains there -- the chain's wait runs out (xerror 2 -> UTM_EHIP) and after utm_reset, which clears the
+    stage words, the same context gives the oracle's rows and float64 scores."""
+    import numpy as np
+    import oracle_util as ou
+    from oracle_util import npo
+    from utmos_amd import device
+    rng = np.random.default_rng(12)
+    n_var, n_samp = 30_000, 90
+    dense = rng.random((n_var, n_samp)) < 0.05
+    dense[:, 0] = rng.random(n_var) < 0.5                     # the best column ...
+    dense[:, 1] = dense[:, 0]                                 # ... twice: an exact tie at the top, chains needed at once
+    dense[np.arange(n_var), rng.integers(2, n_samp, n_var)] = True
+    af = rng.uniform(1e-3, 0.5, n_var)
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8), None, af)
+    monkeypatch.setenv("UTM_TEST_DROP_ARRIVAL", "1")
+    with device.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols)
+        m.set_af(c, af)
+        with pytest.raises(device.nat.NativeError) as e:
+            m.run(n_samp)
+        assert e.value.code == -2
+        monkeypatch.setenv("UTM_TEST_DROP_ARRIVAL", "0")
+        m.reset()
+        got = m.run(n_samp)
+        assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
