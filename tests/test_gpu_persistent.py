@@ -153,3 +153,59 @@ def test_withheld_partial_count_ends_in_an_error_and_the_context_recovers(dev, m
             m.reset()                                   # (re-reads the knobs)
             got = m.run(n_samp)
             assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+
+
+def _af_case(rng, n_var, n_samp, density=0.03):
+    dense = rng.random((n_var, n_samp)) < density
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    # float32 AFs on a narrow exponent range: every sum stays below 2^53 units, the exact fixed-point phase from the start
+    af = (rng.integers(1, 2 * n_samp, n_var) / (2.0 * n_samp)).astype(np.float32)
+    return dense, af
+
+
+@pytest.mark.parametrize("n_var,n_samp,weights", [(60_000, 300, False), (200_000, 120, True), (9_000, 1_200, False), (300_000, 64, False)])
+def test_persistent_af_loop_exact_phase(dev, n_var, n_samp, weights):
+    """The AF form of the persistent loop (float32 AF, exact fixed-point phase, optionally weights): after the first full
+    pass and the dense delta passes the per-sample accumulators are kept current from per-position decreases -- same rows,
+    counts and float64 scores as the oracle, bit for bit, also when the run is cut into calls."""
+    rng = np.random.default_rng(n_var + n_samp)
+    dense, af = _af_case(rng, n_var, n_samp)
+    w = rng.choice([0.5, 1.0, 1.0, 2.0, -1.0], n_samp) if weights else None
+    state = np.ones(n_samp, np.uint8)
+    state[rng.choice(n_samp, n_samp // 12, replace=False)] = 2
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, state, w, af)
+    for pieces in ([n_samp], [5, 1, 70, 256, n_samp]):
+        with dev.DeviceMatrix(n_samp) as m:
+            c = m.add_chunk(n_var)
+            m.upload_columns(c, cols)
+            m.set_af(c, af)
+            m.set_state(state)
+            m.set_weights(w)
+            idx, new, score = [], [], []
+            for piece in pieces:
+                got = m.run(piece)
+                idx += got[0].tolist(); new += got[1].tolist(); score += got[2].tolist()
+            st = m.stats()
+        assert idx == exp[0].tolist() and new == exp[1].tolist()
+        assert score == exp[2].tolist()                          # float64 scores, bit for bit
+        assert st["af_fixed_point"] == 1
+        assert st["persist_iterations"] > 0.5 * len(idx), st    # most of the run went through k_loop_int<.., AF>
+
+
+def test_persistent_af_loop_can_be_switched_off_and_float64_af_keeps_the_launches(dev, monkeypatch):
+    rng = np.random.default_rng(77)
+    dense, af = _af_case(rng, 50_000, 200)
+    cols = npo.pack_columns(dense)
+    state = np.ones(200, np.uint8)
+    for af_values, env, expect in ((af, "1", True), (af, "0", False), (af.astype(np.float64) / 3.0, "1", False)):
+        monkeypatch.setenv("UTM_PERSIST_AF", env)
+        exp = ou.c_greedy(cols, 50_000, state, None, af_values)
+        with dev.DeviceMatrix(200) as m:
+            c = m.add_chunk(50_000)
+            m.upload_columns(c, cols)
+            m.set_af(c, af_values)
+            got = m.run(200)
+            st = m.stats()
+        assert got[0].tolist() == exp[0].tolist() and got[2].tolist() == exp[2].tolist()
+        assert (st["persist_iterations"] > 0) == expect, st

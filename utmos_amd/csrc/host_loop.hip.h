@@ -154,29 +154,35 @@ struct LoopShape {
     int steps = 8;
     unsigned q_slots = 0, n_tiles = 0;
 };
-static LoopShape loop_shape(utm_ctx *c)
+// af: the caller has established the AF form's preconditions (loop_af_ready); otherwise AF and weights keep the launches.
+static LoopShape loop_shape(utm_ctx *c, bool af = false)
 {
     LoopShape sh;
     const Tune &tn = c->tune;
-    if (!tn.persistent || c->persist_off || c->af_mode != UTM_AF_NONE || c->have_weights || c->decr_enabled || c->chunks.size() != 1 ||
+    if (!tn.persistent || c->persist_off || (!af && (c->af_mode != UTM_AF_NONE || c->have_weights)) || c->decr_enabled || c->chunks.size() != 1 ||
         c->n_ranks != 1 || c->n_local != c->n_total || c->comm || c->p2p || c->n_local >= UTM_LOOP_MAX_LOCAL ||
         (tn.persist_max_samples > 0 && c->n_local > (unsigned)tn.persist_max_samples))
         return sh;
     const Chunk &ch = c->chunks[0];
     if (tn.persist_max_mb > 0 && (u64)c->n_local * ch.wp * 8 > ((u64)tn.persist_max_mb << 20)) return sh;
-    static int cus = 0, occ[4] = {0, 0, 0, 0};  // resident blocks per CU for the 8 / 16 / 32 / 64 KiB tile
+    static int cus = 0, occ_all[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // resident blocks per CU for the 8 / 16 / 32 / 64 KiB tile, integer / AF form
     if (!cus) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return sh;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[0], k_loop_int<8, true>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[1], k_loop_int<16, true>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], k_loop_int<32, true>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[3], k_loop_int<64, true>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][0], k_loop_int<8, true, false>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][1], k_loop_int<16, true, false>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][2], k_loop_int<32, true, false>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][3], k_loop_int<64, true, false>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][0], k_loop_int<8, true, true>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][1], k_loop_int<16, true, true>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][2], k_loop_int<32, true, true>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][3], k_loop_int<64, true, true>, UTM_LOOP_THREADS, 0);
         cus = prop.multiProcessorCount;
         if (getenv("UTM_VERBOSE"))
-            fprintf(stderr, "libutmos_hip: k_loop_int occupancy query: %d / %d / %d / %d blocks of %d threads per CU (8 / 16 / 32 / 64 KiB tile), %d CUs\n",
-                    occ[0], occ[1], occ[2], occ[3], UTM_LOOP_THREADS, cus);
+            fprintf(stderr, "libutmos_hip: k_loop_int occupancy query: %d / %d / %d / %d (AF form %d / %d / %d / %d) blocks of %d threads per CU (8 / 16 / 32 / 64 KiB tile), %d CUs\n",
+                    occ_all[0][0], occ_all[0][1], occ_all[0][2], occ_all[0][3], occ_all[1][0], occ_all[1][1], occ_all[1][2], occ_all[1][3], UTM_LOOP_THREADS, cus);
     }
+    const int *occ = occ_all[af ? 1 : 0];
     // Tile: the smallest of 8 / 16 / 32 / 64 KiB that cuts a column into at most persist_max_tiles tiles -- every (position,
     // tile) pair costs one atomic on the position's count word, 16 count words share a cache line, and beyond ~30 tiles
     // those lines become the bottleneck (measured: 2,504 samples, 31 tiles +3.5 %, 39 tiles -2 %, 153 tiles -15 % against
@@ -202,9 +208,26 @@ static LoopShape loop_shape(utm_ctx *c)
 }
 
 // Up to k_batch iterations as ONE launch (k_loop_int): the picker's record replaces the kernel boundary.
-static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch)
+// The AF form of the persistent loop applies in the exact fixed-point phase: float32 AF on a lossless unit, every
+// selectable sample's sum below 2^53 units (latched from the device: af_all_exact -- the plain exact pick suffices, no
+// candidates, no chains, no deferred scores), the per-sample accumulators valid, and the pending winner no longer covering
+// percents of all variants (those first delta passes gather from LDS in k_score_afq; here a gather is a global load).
+static bool loop_af_ready(const utm_ctx *c, bool first_is_full)
+{
+    return c->tune.persist_af && c->af_mode == UTM_AF_F32 && c->af_fixed && !c->af_trunc && c->af_all_exact && c->keep_valid && !first_is_full &&
+           c->last_new >= 0 && (double)c->last_new <= c->tune.af_dense_delta * (double)c->n_var_total;
+}
+
+static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch, bool af = false)
 {
     const Chunk &ch = c->chunks[0];
+    if (af && !c->d_loop_w[0]) {  // the AF form's per-position words: two arrival / count-decrease words, two sum-decrease words
+        const size_t bytes = ((size_t)c->n_local + UTM_PICK_PAD) * 8;
+        for (int i = 0; i < 4; ++i) {
+            HIP_TRY(hipMalloc(&c->d_loop_w[i], bytes));
+            HIP_TRY(hipMemsetAsync(c->d_loop_w[i], 0, bytes, c->stream));
+        }
+    }
     const bool use_nt = c->tune.nt_loads >= 0 ? c->tune.nt_loads != 0 : (u64)c->n_local * c->col_words * 8 > ((u64)c->tune.nt_min_mb << 20);
     // position claim counters: [3 sets, iteration % 3][tiles][wave index], 128 B apart
     const size_t claim_bytes = (size_t)3 * sh.n_tiles * UTM_LOOP_WAVES * UTM_CLAIM_STRIDE * sizeof(unsigned);
@@ -221,19 +244,25 @@ static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch)
     const dim3 grid(sh.n_tiles * sh.q_slots + 1);
     const int drop = c->tune.test_drop_arrival;
     LaunchTimer t(c);
-#define UTM_LAUNCH_LOOP(S, NT)                                                                                                      \
-    UTM_TIMED_LAUNCH(t, (k_loop_int<S, NT>), grid, dim3(UTM_LOOP_THREADS), (const u64 *)ch.cols, ch.covered, ch.wp, pending_of(c, ch, true), c->d_st, \
-                     c->d_act, c->d_cnt, c->d_cnt_alt, sh.q_slots, c->d_claim, k_batch, c->d_loop_sync, pa, drop, c->tune.persist_claims, c->tune.persist_ahead_ticks, c->tune.persist_ahead0_ticks)
+    const LoopAf laf{af ? ch.afx : nullptr, af ? c->d_loop_w[2] : nullptr, af ? c->d_loop_w[3] : nullptr};
+    u64 *w0 = af ? c->d_loop_w[0] : c->d_cnt, *w1 = af ? c->d_loop_w[1] : c->d_cnt_alt;  // (AF: d_cnt holds the per-sample counts)
+#define UTM_LAUNCH_LOOP(S, NT, AFF)                                                                                                 \
+    UTM_TIMED_LAUNCH(t, (k_loop_int<S, NT, AFF>), grid, dim3(UTM_LOOP_THREADS), (const u64 *)ch.cols, ch.covered, ch.wp, pending_of(c, ch, true), c->d_st, \
+                     c->d_act, w0, w1, sh.q_slots, c->d_claim, k_batch, c->d_loop_sync, pa, drop, c->tune.persist_claims, c->tune.persist_ahead_ticks, c->tune.persist_ahead0_ticks, laf)
+#define UTM_LAUNCH_LOOP2(S, NT) \
+    if (af) UTM_LAUNCH_LOOP(S, NT, true); \
+    else UTM_LAUNCH_LOOP(S, NT, false)
     switch (sh.steps * 2 + (use_nt ? 1 : 0)) {
-    case 17: UTM_LAUNCH_LOOP(8, true); break;
-    case 16: UTM_LAUNCH_LOOP(8, false); break;
-    case 33: UTM_LAUNCH_LOOP(16, true); break;
-    case 32: UTM_LAUNCH_LOOP(16, false); break;
-    case 65: UTM_LAUNCH_LOOP(32, true); break;
-    case 64: UTM_LAUNCH_LOOP(32, false); break;
-    case 129: UTM_LAUNCH_LOOP(64, true); break;
-    default: UTM_LAUNCH_LOOP(64, false); break;
+    case 17: UTM_LAUNCH_LOOP2(8, true); break;
+    case 16: UTM_LAUNCH_LOOP2(8, false); break;
+    case 33: UTM_LAUNCH_LOOP2(16, true); break;
+    case 32: UTM_LAUNCH_LOOP2(16, false); break;
+    case 65: UTM_LAUNCH_LOOP2(32, true); break;
+    case 64: UTM_LAUNCH_LOOP2(32, false); break;
+    case 129: UTM_LAUNCH_LOOP2(64, true); break;
+    default: UTM_LAUNCH_LOOP2(64, false); break;
     }
+#undef UTM_LAUNCH_LOOP2
 #undef UTM_LAUNCH_LOOP
     HIP_TRY(hipGetLastError());
     c->persist_launches += 1;
@@ -562,7 +591,10 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     while (enq < k_max && !c->finished) {
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
         // ... and so is the switch to decremental iterations
-        const i64 this_batch = (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, c->iter < 8 ? 4 : 8)
+        // (the AF form of the persistent loop needs no host decision inside a batch: 256 iterations per launch, as for integers)
+        const bool loop_af_batch = batch_env <= 0 && !c->decr_enabled && loop_af_ready(c, false) && loop_shape(c, true).ok;
+        const i64 this_batch = loop_af_batch                                                  ? 256
+                               : (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, c->iter < 8 ? 4 : 8)
                                : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, decr_first)
                                                                                             : batch;
         const i64 n = std::min<i64>(this_batch, k_max - enq);
@@ -584,8 +616,9 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // where the pick runs: inside the scoring launch on the only shard (1) and on a shard of the mailbox exchange (2)
         const int fuse_mode = mailbox_exchange(c) ? 2 : (c->n_ranks == 1 && c->n_local == c->n_total && !c->comm) ? 1 : 0;
         // short scans (and any matrix whose tile grid fits the resident blocks): the whole batch as ONE persistent launch
-        const LoopShape loop = (!decr && fuse_mode == 1 && c->tune.fuse_pick) ? loop_shape(c) : LoopShape();
-        if (loop.ok) TRY(enqueue_loop(c, loop, (int)n));
+        const bool loop_af = af_par && loop_af_ready(c, first_is_full);
+        const LoopShape loop = (!decr && fuse_mode == 1 && c->tune.fuse_pick && (c->af_mode == UTM_AF_NONE || loop_af)) ? loop_shape(c, loop_af) : LoopShape();
+        if (loop.ok) TRY(enqueue_loop(c, loop, (int)n, loop_af));
         for (i64 j = 0; j < n && !loop.ok; ++j) {
             bool picked = false;
             c->enq_iter = c->iter + j;  // (exact unless the loop ends first -- and then these launches do nothing)

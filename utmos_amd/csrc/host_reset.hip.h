@@ -118,6 +118,8 @@ extern "C" int utm_reset(utm_ctx *c)
     if (!act.empty()) HIP_TRY(hipMemcpyAsync(c->d_act, act.data(), act.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_cnt_alt, 0, (size_t)c->n_local * 8, c->stream));  // (a launch that ended on an error may have left partial counts)
+    for (auto *w : c->d_loop_w)
+        if (w) HIP_TRY(hipMemsetAsync(w, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_fscore, 0, (size_t)c->n_local * 8, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_arrivals, 0, 128, c->stream));

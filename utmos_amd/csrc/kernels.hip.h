@@ -4,8 +4,8 @@
 #include "common.hip.h"
 #include "pick.hip.h"
 #include "score_int.hip.h"
-#include "loop_int.hip.h"
 #include "score_af.hip.h"
+#include "loop_int.hip.h"
 #include "covered.hip.h"
 #include "decremental.hip.h"
 #include "af_verify.hip.h"

@@ -67,6 +67,11 @@ static_assert(sizeof(LoopSync) % 16 == 0, "zeroed by one memset");
 #define UTM_LOOP_E 5  // count words a picker thread keeps in flight (x UTM_LOOP_THREADS = one chunk)
 #endif
 #define UTM_CLAIM_STRIDE 32  // claim counters are 128 B apart
+// AF form: a count word = decrease:40 | partials arrived:12 | non-empty partials among them:12; a sum word = decrease:56 |
+// non-empty partials arrived:8 (at most 64 tiles; a decrease stays below 2^53 units) -- the picker takes a position when
+// the first shows all tiles and the second shows as many arrivals as the first announces
+#define UTM_NONEMPTY_SHIFT 52
+#define UTM_AFD_ARRIVAL_SHIFT 56
 #define UTM_COLS_SLACK_BYTES (64u << 10)  // zeros behind a chunk's last column (whole-batch reads of a short last tile)
 #define UTM_LOOP_EPOCH_MASK 0xFFFFFFull
 #define UTM_LOOP_MAX_LOCAL (1u << 28)    // best_pos / moved are 28-bit fields
@@ -97,6 +102,7 @@ __device__ __forceinline__ LoopRec loop_read_record(const LoopSync *sync, unsign
 // ------------------------------------------------------------------------------------------------ the picker
 struct LoopPickLds {
     IntCand wbest[UTM_LOOP_WAVES];
+    double wval[UTM_LOOP_WAVES];  // (AF: the waves' best scores; count / sample / position travel in wbest)
     unsigned n_active;
     int stop, failed, pad;
     unsigned best_pos, moved;  // the decision's change to act[] (every thread keeps its own entries current)
@@ -111,8 +117,23 @@ __device__ __forceinline__ void loop_publish(LoopSync *sync, unsigned epoch, int
     __hip_atomic_store(&sync->pub[0], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u64 *cnt0, u64 *cnt1, unsigned *claim, unsigned n_tiles,
-                                            unsigned n_blocks, int k_batch, LoopPickLds *L)
+// AF = false: scores are the counts themselves (unweighted integer loop).  AF = true: the exact fixed-point AF phase
+// (float32 values, every sum below 2^53 units: DESIGN.md section 4 "Exactness") and / or per-sample weights -- the count
+// words carry this iteration's DECREASE of a position's count (what the pending winner newly covered of it), afd0 / afd1
+// the decrease of its fixed-point sum (added, by a returning atomic, BEFORE the count word's arrival: the word certifies
+// both); the picker keeps the per-sample accumulators (a.cnt / a.afsum, by sample) current and compares float64 scores.
+struct AfCand {
+    double val;
+    u64 cnt;
+    unsigned s, pos;
+};
+__device__ __forceinline__ bool better_af(const AfCand &a, const AfCand &b)
+{
+    return a.val > b.val || (a.val == b.val && a.s < b.s);
+}
+template <bool AF>
+__device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u64 *cnt0, u64 *cnt1, u64 *afd0, u64 *afd1, unsigned *claim,
+                                            unsigned n_tiles, unsigned n_blocks, int k_batch, LoopPickLds *L)
 {
     IterState *st = a.st;
     const int lane = threadIdx.x & 63;
@@ -148,8 +169,12 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
     // decisions themselves -- a picker iteration then starts polling without a round trip to memory
     const bool one_chunk = n_active <= UTM_LOOP_THREADS * UTM_LOOP_E;
     unsigned s[UTM_LOOP_E];
+    u64 c_keep[UTM_LOOP_E], a_keep[UTM_LOOP_E];  // (AF: the accumulators of this thread's samples)
 #pragma unroll
-    for (int e = 0; e < UTM_LOOP_E; ++e) s[e] = 0;
+    for (int e = 0; e < UTM_LOOP_E; ++e) {
+        s[e] = 0;
+        c_keep[e] = a_keep[e] = 0;
+    }
     u64 t_pub = wall_clock64(), t_work = 0;  // when the last record went out; how long after ITS predecessor the last iteration's counts were complete (100 MHz ticks)
     for (int k = 0;; ++k) {
         u64 *cnt = (k & 1) ? cnt1 : cnt0;
@@ -161,7 +186,9 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
             while ((u64)wall_clock64() < until) __builtin_amdgcn_s_sleep(16);
         }
         IntCand best{0, 0xFFFFFFFFu, 0};
+        AfCand fbest{-__builtin_inf(), 0, 0xFFFFFFFFu, 0};
         int failed = 0;
+        u64 *afd = (k & 1) ? afd1 : afd0;
         // UTM_LOOP_E words per thread in flight, EVERY incomplete word of the chunk re-read every round: once the last
         // partial has landed, the next round sees the chunk complete (2,504 samples are one chunk)
         for (unsigned base = 0; base < n_active && !failed; base += UTM_LOOP_THREADS * UTM_LOOP_E) {
@@ -171,8 +198,15 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
             for (int e = 0; e < UTM_LOOP_E; ++e) {
                 const unsigned i = i0 + e * UTM_LOOP_THREADS;
                 const bool in = i < n_active;
-                // (one chunk: this thread's entries of act[] stay in its registers from iteration to iteration, see below)
-                if (!one_chunk || k == 0) s[e] = in ? __hip_atomic_load(&a.act[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                // (one chunk: this thread's entries of act[] -- and, AF, their accumulators -- stay in its registers from
+                // iteration to iteration, see below)
+                if (!one_chunk || k == 0) {
+                    s[e] = in ? __hip_atomic_load(&a.act[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    if (AF && in) {
+                        c_keep[e] = __hip_atomic_load(&a.cnt[s[e]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a_keep[e] = __hip_atomic_load(reinterpret_cast<u64 *>(&a.afsum[s[e]]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
                 if (in) need |= 1u << e;
             }
             u64 *words = cnt + i0;
@@ -183,10 +217,36 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                     v[e] = (need >> e & 1) ? __hip_atomic_fetch_add(words + e * UTM_LOOP_THREADS, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
 #pragma unroll
                 for (int e = 0; e < UTM_LOOP_E; ++e) {
-                    const bool fin = (need >> e & 1) && (v[e] >> UTM_ARRIVAL_SHIFT) == n_tiles;
+                    bool fin = (need >> e & 1) && ((v[e] >> UTM_ARRIVAL_SHIFT) & 0xFFFu) == n_tiles;
+                    u64 d_af = 0;
+                    if (AF && fin && (v[e] >> UTM_NONEMPTY_SHIFT)) {
+                        // the sum word: complete when it shows as many arrivals as the count word announces (else next round)
+                        u64 *dw = afd + i0 + e * UTM_LOOP_THREADS;
+                        const u64 aw = __hip_atomic_load(dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((aw >> UTM_AFD_ARRIVAL_SHIFT) == (v[e] >> UTM_NONEMPTY_SHIFT)) {
+                            d_af = aw & ((1ull << UTM_AFD_ARRIVAL_SHIFT) - 1);
+                            __hip_atomic_store(dw, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            fin = false;
+                        }
+                    }
                     if (fin) __hip_atomic_store(words + e * UTM_LOOP_THREADS, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (next used two iterations on)
-                    const IntCand cand{fin ? (v[e] & count_mask) : 0ull, fin ? s[e] : 0xFFFFFFFFu, i0 + e * UTM_LOOP_THREADS};
-                    if (better_int(cand, best)) best = cand;
+                    if (!AF) {
+                        const IntCand cand{fin ? (v[e] & count_mask) : 0ull, fin ? s[e] : 0xFFFFFFFFu, i0 + e * UTM_LOOP_THREADS};
+                        if (better_int(cand, best)) best = cand;
+                    } else if (fin) {
+                        const u64 d_cnt = v[e] & count_mask;
+                        if (d_cnt) {
+                            c_keep[e] -= d_cnt;
+                            a_keep[e] -= d_af;
+                            __hip_atomic_store(&a.cnt[s[e]], c_keep[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(reinterpret_cast<u64 *>(&a.afsum[s[e]]), a_keep[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        double val = (double)(i64)a_keep[e] * a.af_scale;  // exact: < 2^53 units, power-of-two scale
+                        if (a.weights) val *= a.weights[a.first + s[e]];
+                        const AfCand cand{val, c_keep[e], s[e], i0 + e * UTM_LOOP_THREADS};
+                        if (better_af(cand, fbest)) fbest = cand;
+                    }
                     need &= ~((fin ? 1u : 0u) << e);
                 }
                 if (need) {
@@ -197,17 +257,30 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            IntCand other;
-            other.cnt = __shfl_xor(best.cnt, o, 64);
-            other.s = __shfl_xor(best.s, o, 64);
-            other.pos = __shfl_xor(best.pos, o, 64);
-            if (better_int(other, best)) best = other;
+            if (!AF) {
+                IntCand other;
+                other.cnt = __shfl_xor(best.cnt, o, 64);
+                other.s = __shfl_xor(best.s, o, 64);
+                other.pos = __shfl_xor(best.pos, o, 64);
+                if (better_int(other, best)) best = other;
+            } else {
+                AfCand other;
+                other.val = __shfl_xor(fbest.val, o, 64);
+                other.cnt = __shfl_xor(fbest.cnt, o, 64);
+                other.s = __shfl_xor(fbest.s, o, 64);
+                other.pos = __shfl_xor(fbest.pos, o, 64);
+                if (better_af(other, fbest)) fbest = other;
+            }
         }
         t_work = (u64)wall_clock64() - t_pub;  // (this thread's words; all threads finish within a round of each other)
         if (threadIdx.x == 0) L->failed = 0;
         if (threadIdx.x == 0) UTM_LSTAMP(sync, k, 0);
         __syncthreads();
-        if (lane == 0) L->wbest[threadIdx.x >> 6] = best;
+        if (AF) best = IntCand{fbest.cnt, fbest.s, fbest.pos};
+        if (lane == 0) {
+            L->wbest[threadIdx.x >> 6] = best;
+            if (AF) L->wval[threadIdx.x >> 6] = fbest.val;
+        }
         if (failed) L->failed = 1;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -220,10 +293,24 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                 stop = 1;
                 loop_publish(sync, epoch, 1, 0, 0, 0, 0);
             } else {
-                for (int w8 = 1; w8 < UTM_LOOP_WAVES; ++w8)
-                    if (better_int(L->wbest[w8], best)) best = L->wbest[w8];
-                // decide_single, on the loop state this thread carries in registers
-                if (n_active == 0 || best.cnt == 0) {  // (unweighted integer scores are never negative)
+                double best_val = AF ? fbest.val : 0.0;
+                for (int w8 = 1; w8 < UTM_LOOP_WAVES; ++w8) {
+                    if (!AF) {
+                        if (better_int(L->wbest[w8], best)) best = L->wbest[w8];
+                    } else {
+                        const AfCand o{L->wval[w8], L->wbest[w8].cnt, L->wbest[w8].s, L->wbest[w8].pos};
+                        const AfCand m{best_val, best.cnt, best.s, best.pos};
+                        if (better_af(o, m)) {
+                            best = L->wbest[w8];
+                            best_val = o.val;
+                        }
+                    }
+                }
+                if (!AF) best_val = (double)best.cnt;
+                // decide_single, on the loop state this thread carries in registers (a negative best score only wins when
+                // no sample holds a masked 0: select.py:43-48)
+                const bool zero_elsewhere = n_active_total < (i64)a.n_total;
+                if (n_active == 0 || (AF ? (best_val == 0.0 || (best_val < 0.0 && zero_elsewhere)) : best.cnt == 0)) {
                     st->done = 1;  // (None, None): no row (select.py:51-52, :93-96)
                     a.res_idx[iter] = -1;
                     stop = 1;
@@ -238,7 +325,7 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                     __hip_atomic_store(&a.act[best.pos], moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     a.res_idx[iter] = (i64)a.first + best.s;
                     a.res_new[iter] = (i64)best.cnt;
-                    a.res_score[iter] = (double)best.cnt;
+                    a.res_score[iter] = best_val;
                     a.state[best.s] = 0;  // sample_mask[use_sample] = 0 (select.py:100)
                     iter += 1;
                     tot += (i64)best.cnt;
@@ -251,7 +338,7 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                     st->best_pos = best.pos;
                     if (finished) st->done = 1;
                     Rec *rc = rec_of(a, a.rank);
-                    rc->score = (double)best.cnt;
+                    rc->score = best_val;
                     rc->idx = (i64)a.first + best.s;
                     rc->new_count = (i64)best.cnt;
                     if (!stop) {
@@ -290,7 +377,13 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
             const unsigned bp = L->best_pos, mv = L->moved;
 #pragma unroll
             for (int e = 0; e < UTM_LOOP_E; ++e)
-                if (threadIdx.x + e * UTM_LOOP_THREADS == bp) s[e] = mv;
+                if (threadIdx.x + e * UTM_LOOP_THREADS == bp) {
+                    s[e] = mv;
+                    if (AF) {  // (whoever held that sample stored every change; the barrier and vmcnt(0) above order it)
+                        c_keep[e] = __hip_atomic_load(&a.cnt[mv], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a_keep[e] = __hip_atomic_load(reinterpret_cast<u64 *>(&a.afsum[mv]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
         }
     }
 }
@@ -307,14 +400,25 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
 // count -- which is why the picker may reset an iteration's counters as soon as all its count words are complete.
 // drop_iter: test hook (0 = off) -- the first worker withholds one partial count in that iteration of the launch, so
 // that the picker's bounded wait runs out.
-template <int STEPS, bool NT>
+// AF: the delta form of the exact fixed-point AF phase.  The per-sample accumulators (count, fixed-point sum) are valid
+// when the launch starts; an iteration subtracts what its pending winner newly covers: the worker keeps a second LDS tile,
+// newly = live & winner (made for free while the tile is updated), counts column & newly instead of column & live, and
+// gathers the fixed-point AF entries of the few surviving bits from the table in global memory (afbits; L2 / Infinity
+// Cache resident).  Same bytes streamed as the integer loop, same hand-off.
+struct LoopAf {
+    const unsigned *afbits;  // this chunk's fixed-point table (af_fixed), or nullptr
+    u64 *afd0, *afd1;        // per position: this iteration's decrease of the fixed-point sum (by iteration parity)
+};
+template <int STEPS, bool NT, bool AF>
 __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp, const Pending pend,
                                                   IterState *__restrict__ st, unsigned *__restrict__ act, u64 *__restrict__ cnt0,
                                                   u64 *__restrict__ cnt1, unsigned q_slots, unsigned *__restrict__ claim, int k_batch,
-                                                  LoopSync *__restrict__ sync, const PickArgs pa, int drop_iter, int use_claims, int ahead_ticks, int ahead0_ticks)
+                                                  LoopSync *__restrict__ sync, const PickArgs pa, int drop_iter, int use_claims, int ahead_ticks, int ahead0_ticks,
+                                                  const LoopAf laf)
 {
     static_assert(STEPS % 8 == 0 && STEPS <= 64, "a tile is 1..8 batches of 8 KiB");
     __shared__ v4u live[STEPS * 64];  // ~covered of this worker's tile (STEPS KiB), for the whole launch
+    __shared__ v4u newly_lds[AF ? STEPS * 64 : 1];  // AF: what the pending winner newly covers of the tile
     __shared__ LoopRec rec_lds;
     __shared__ unsigned rec_epoch_lds;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -326,7 +430,7 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
     constexpr unsigned TILE_WORDS = STEPS * UTM_STEP_WORDS;
     const unsigned n_tiles = (unsigned)((wp + TILE_WORDS - 1) / TILE_WORDS);
     if (blockIdx.x == 0) {
-        loop_picker(pa, sync, cnt0, cnt1, claim, n_tiles, gridDim.x, k_batch, reinterpret_cast<LoopPickLds *>(&live[0]));
+        loop_picker<AF>(pa, sync, cnt0, cnt1, laf.afd0, laf.afd1, claim, n_tiles, gridDim.x, k_batch, reinterpret_cast<LoopPickLds *>(&live[0]));
         return;
     }
     if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync->arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -349,11 +453,36 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
     }
 #define UTM_BATCH_COUNT(X, J)                                                                        \
     {                                                                                                \
-        const v4u *l_ = &live[(J) * 8 * 64 + lane];                                                  \
-        _Pragma("unroll") for (int q = 0; q < U; ++q)                                                \
-        {                                                                                            \
-            const v4u b = X[q] & l_[q * 64];                                                         \
-            acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                            \
+        const v4u *l_ = (AF ? &newly_lds[(J) * 8 * 64 + lane] : &live[(J) * 8 * 64 + lane]);         \
+        if (!AF) {                                                                                   \
+            _Pragma("unroll") for (int q = 0; q < U; ++q)                                            \
+            {                                                                                        \
+                const v4u b = X[q] & l_[q * 64];                                                     \
+                acc += __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);                        \
+            }                                                                                        \
+        } else {                                                                                     \
+            unsigned nb_ = 0;                                                                        \
+            _Pragma("unroll") for (int q = 0; q < U; ++q)                                            \
+            {                                                                                        \
+                X[q] &= l_[q * 64];                                                                  \
+                nb_ += __popc(X[q].x) + __popc(X[q].y) + __popc(X[q].z) + __popc(X[q].w);            \
+            }                                                                                        \
+            acc += nb_;                                                                              \
+            if (__ballot(nb_ != 0) != 0) { /* rare once coverage has grown: walk the surviving bits */ \
+                const unsigned *af_ = laf.afbits + (w0 + (u64)(J) * 8 * UTM_STEP_WORDS + 2 * lane) * 64; \
+                _Pragma("unroll") for (int q = 0; q < U; ++q)                                        \
+                {                                                                                    \
+                    _Pragma("unroll") for (int d = 0; d < 4; ++d)                                    \
+                    {                                                                                \
+                        unsigned bits = X[q][d];                                                     \
+                        const unsigned *a_ = af_ + q * (UTM_STEP_WORDS * 64) + d * 32;               \
+                        while (bits) {                                                               \
+                            afacc += af_fixed(a_[__builtin_ctz(bits)]);                              \
+                            bits &= bits - 1;                                                        \
+                        }                                                                            \
+                    }                                                                                \
+                }                                                                                    \
+            }                                                                                        \
         }                                                                                            \
     }
     // A wave's work in an iteration is a STREAM of batches: all nb batches of its first position, of its second, then of
@@ -380,13 +509,18 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
         const v4u *cv = reinterpret_cast<const v4u *>(covered + w0);
         const u64 *wcol = pend.fuse ? pending_column(&head, cols, wp, pend) : nullptr;
         const v4u *wc = wcol ? reinterpret_cast<const v4u *>(wcol + w0) : nullptr;
+        const v4u zero4 = {0, 0, 0, 0};
         for (int k = threadIdx.x; k < nsteps * 64; k += UTM_LOOP_THREADS) {
             v4u c = cv[k];
-            if (wc) c |= wc[k];
+            const v4u w = wc ? wc[k] : zero4;
+            if (AF) newly_lds[k] = w & ~c;  // the first iteration's delta: the winner that is pending when the launch starts
+            c |= w;
             live[k] = ~c;
         }
-        const v4u zero4 = {0, 0, 0, 0};
-        for (int k = nsteps * 64 + threadIdx.x; k < STEPS * 64; k += UTM_LOOP_THREADS) live[k] = zero4;  // (a short tile's missing steps)
+        for (int k = nsteps * 64 + threadIdx.x; k < STEPS * 64; k += UTM_LOOP_THREADS) {  // (a short tile's missing steps)
+            live[k] = zero4;
+            if (AF) newly_lds[k] = zero4;
+        }
     }
     // the census verdict
     if (threadIdx.x == 0) {
@@ -420,7 +554,15 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
 #define UTM_PARTIAL(POS, ACC, DROP)                                                                                    \
     {                                                                                                                  \
         const unsigned sum_ = wave_sum_u32(ACC);                                                                       \
-        if (lane == 0 && !(DROP)) atomicAdd(&cnt[POS], (u64)sum_ + (1ull << UTM_ARRIVAL_SHIFT));                       \
+        u64 word_ = (u64)sum_ + (1ull << UTM_ARRIVAL_SHIFT);                                                           \
+        if (AF && sum_) { /* a non-empty partial: the sum's decrease travels in a word of its own, self-certifying too */ \
+            const u64 tot_ = (u64)wave_sum_u63(afacc);                                                                 \
+            u64 *afd_ = (k & 1) ? laf.afd1 : laf.afd0;                                                                 \
+            if (lane == 0) atomicAdd(&afd_[POS], tot_ + (1ull << UTM_AFD_ARRIVAL_SHIFT));                              \
+            word_ += 1ull << UTM_NONEMPTY_SHIFT; /* ... and the count word says how many such partials to expect */    \
+            afacc = 0;                                                                                                 \
+        }                                                                                                              \
+        if (lane == 0 && !(DROP)) atomicAdd(&cnt[POS], word_);                                                         \
     }
     const unsigned none = 0xFFFFFFFFu;
     for (int k = 0;; ++k) {
@@ -505,6 +647,8 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
             UTM_IT_NEXT(pos_b, j_b, s_dummy)
             (void)s_dummy;
             unsigned acc = 0;
+            u64 afacc = 0;  // (AF: this lane's fixed-point sum over the position's newly covered bits)
+            (void)afacc;
             // one step: count buffer X (batch J of position POS; a position's last batch sends its partial count), then
             // refill it with the stream's next batch (the queue's requests, if any, go out first)
 #define UTM_LOOP_STEP(X, POS, J)                                                                                           \
@@ -604,7 +748,11 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
         // covered |= winner, in LDS: live &= ~winner's tile
         {
             const v4u *wc = reinterpret_cast<const v4u *>(cols + (u64)r.winner * wp + w0);
-            for (int kk = threadIdx.x; kk < nsteps * 64; kk += UTM_LOOP_THREADS) live[kk] &= ~wc[kk];
+            for (int kk = threadIdx.x; kk < nsteps * 64; kk += UTM_LOOP_THREADS) {
+                const v4u w = wc[kk], l = live[kk];
+                if (AF) newly_lds[kk] = l & w;
+                live[kk] = l & ~w;
+            }
         }
         if (r.removed) {
             n_act -= 1;

@@ -126,7 +126,7 @@ struct Tune {
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
-    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, test_drop_arrival;
+    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, persist_af, test_drop_arrival;
     int mbox_spins_log2, test_mute_exchange;                                 // mailbox exchange: patience, test hook   // persistent loop kernel
 };
 struct KnobDef {
@@ -165,6 +165,7 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_PERSIST_MAX_TILES", persist_max_tiles, 32),
     UTM_KNOB_I("UTM_PERSIST_TILE_KIB", persist_tile_kib, 0),
     UTM_KNOB_I("UTM_PERSIST_MAX_SAMPLES", persist_max_samples, 2560),  // (one chunk of count words for the picker: UTM_LOOP_THREADS x UTM_LOOP_E)
+    UTM_KNOB_I("UTM_PERSIST_AF", persist_af, 1),  // the AF form (exact float32 phase) of the persistent loop
     UTM_KNOB_I("UTM_PERSIST_CLAIMS", persist_claims, 1),
     UTM_KNOB_I("UTM_PERSIST_AHEAD0_TICKS", persist_ahead0_ticks, 0),
     UTM_KNOB_I("UTM_PERSIST_AHEAD_TICKS", persist_ahead_ticks, 400),  // 10 ns ticks: the second run-ahead batch goes out this long before the record is due (0: at once)
@@ -241,6 +242,7 @@ struct utm_ctx {
     u64 *d_cnt = nullptr;              // n_local
     u64 *d_cnt_alt = nullptr;          // persistent loop: the count words of odd iterations (loop_int.hip.h)
     LoopSync *d_loop_sync = nullptr;   // ... its census counters and the picker's record
+    u64 *d_loop_w[4] = {nullptr, nullptr, nullptr, nullptr};  // ... AF form: per-position count-decrease (2) and sum-decrease (2) words
     unsigned *d_claim = nullptr;       // ... its position claim counters (sized for the tile grid at the first launch)
     size_t claim_bytes = 0;
     bool persist_off = false;          // ... a census failed on this context (not every block resident): launch per iteration from now on
@@ -471,6 +473,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
     (void)hipFree(c->d_cnt_alt); (void)hipFree(c->d_loop_sync); (void)hipFree(c->d_claim);
+    for (auto *w : c->d_loop_w) (void)hipFree(w);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
     (void)hipFree(c->d_xbuf); (void)hipFree(c->d_wincol); (void)hipFree(c->d_stage); (void)hipFree(c->d_seq); (void)hipFree(c->d_seq_alt); (void)hipFree(c->d_varcount);
