@@ -29,6 +29,9 @@
 // counters.  Columns are immutable.  Count words alternate between two buffers by iteration parity, so the picker's
 // clearing stores have a whole iteration to land before the words are added to again.
 //
+// AF form (template parameter AF, below): the exact float32-AF phase as delta iterations on per-sample accumulators -- a
+// second LDS tile holds what the pending winner newly covers, the words carry decreases.
+//
 // Residency.  Waiting on another workgroup is only safe when it is running: the launch starts with a CENSUS (every
 // block counts in on its XCD slot's counter; the picker waits -- bounded -- for all of them, then says go or abort).
 // After an abort nothing has been touched; the host falls back to one launch per iteration and stops trying.
