@@ -209,3 +209,30 @@ def test_persistent_af_loop_can_be_switched_off_and_float64_af_keeps_the_launche
             st = m.stats()
         assert got[0].tolist() == exp[0].tolist() and got[2].tolist() == exp[2].tolist()
         assert (st["persist_iterations"] > 0) == expect, st
+
+
+@pytest.mark.parametrize("kind", ["positive", "signed", "all_negative", "with_zero"])
+def test_persistent_loop_with_weights(dev, kind):
+    """Integer counts times per-sample weights inside the persistent loop (the picker compares float64 products): signed and
+    zero weights, the negative-best rule (a negative product only wins when no sample holds a masked 0: select.py:43-48)."""
+    rng = np.random.default_rng(len(kind))
+    n_var, n_samp = 40_000, 260
+    dense = ou.random_dense(rng, n_var, n_samp, density=0.02)
+    w = {"positive": rng.choice([0.5, 1.0, 2.0, 3.5], n_samp),
+         "signed": rng.choice([-2.0, -0.5, 1.0, 2.0], n_samp),
+         "all_negative": -rng.choice([0.5, 1.0, 2.0], n_samp),
+         "with_zero": rng.choice([0.0, 1.0, 1.0, 2.0], n_samp)}[kind]
+    state = np.ones(n_samp, np.uint8)
+    if kind != "all_negative":
+        state[rng.choice(n_samp, 20, replace=False)] = 2
+    cols = npo.pack_columns(dense)
+    exp = ou.c_greedy(cols, n_var, state, w)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols)
+        m.set_state(state)
+        m.set_weights(w)
+        got = m.run(n_samp)
+        st = m.stats()
+    assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
+    assert st["persist_iterations"] == st["iterations"] or len(exp[0]) == 0

@@ -154,12 +154,13 @@ struct LoopShape {
     int steps = 8;
     unsigned q_slots = 0, n_tiles = 0;
 };
-// af: the caller has established the AF form's preconditions (loop_af_ready); otherwise AF and weights keep the launches.
+// af: the caller has established the AF form's preconditions (loop_af_ready); otherwise AF runs keep the launches.
+// (Weighted integer scores take the loop too: the picker compares float64 products.)
 static LoopShape loop_shape(utm_ctx *c, bool af = false)
 {
     LoopShape sh;
     const Tune &tn = c->tune;
-    if (!tn.persistent || c->persist_off || (!af && (c->af_mode != UTM_AF_NONE || c->have_weights)) || c->decr_enabled || c->chunks.size() != 1 ||
+    if (!tn.persistent || c->persist_off || (!af && c->af_mode != UTM_AF_NONE) || c->decr_enabled || c->chunks.size() != 1 ||
         c->n_ranks != 1 || c->n_local != c->n_total || c->comm || c->p2p || c->n_local >= UTM_LOOP_MAX_LOCAL ||
         (tn.persist_max_samples > 0 && c->n_local > (unsigned)tn.persist_max_samples))
         return sh;

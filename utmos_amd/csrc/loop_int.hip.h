@@ -134,10 +134,14 @@ __device__ __forceinline__ bool better_af(const AfCand &a, const AfCand &b)
 {
     return a.val > b.val || (a.val == b.val && a.s < b.s);
 }
-template <bool AF>
+// MODE 0: unweighted integer scores.  1: the AF form.  2: integer counts times per-sample weights (full counts in the
+// words as in MODE 0, float64 products compared as in MODE 1).
+template <int MODE>
 __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u64 *cnt0, u64 *cnt1, u64 *afd0, u64 *afd1, unsigned *claim,
                                             unsigned n_tiles, unsigned n_blocks, int k_batch, LoopPickLds *L)
 {
+    constexpr bool AF = MODE == 1;   // decrease words, per-sample accumulators
+    constexpr bool DBL = MODE != 0;  // float64 scores: (score descending, sample ascending), the negative-best rule
     IterState *st = a.st;
     const int lane = threadIdx.x & 63;
     // census: every block of the grid (this one included) has counted in => every block is resident
@@ -234,20 +238,21 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                         }
                     }
                     if (fin) __hip_atomic_store(words + e * UTM_LOOP_THREADS, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (next used two iterations on)
-                    if (!AF) {
+                    if (!DBL) {
                         const IntCand cand{fin ? (v[e] & count_mask) : 0ull, fin ? s[e] : 0xFFFFFFFFu, i0 + e * UTM_LOOP_THREADS};
                         if (better_int(cand, best)) best = cand;
                     } else if (fin) {
                         const u64 d_cnt = v[e] & count_mask;
-                        if (d_cnt) {
+                        if (AF && d_cnt) {
                             c_keep[e] -= d_cnt;
                             a_keep[e] -= d_af;
                             __hip_atomic_store(&a.cnt[s[e]], c_keep[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(reinterpret_cast<u64 *>(&a.afsum[s[e]]), a_keep[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        double val = (double)(i64)a_keep[e] * a.af_scale;  // exact: < 2^53 units, power-of-two scale
+                        const u64 count = AF ? c_keep[e] : d_cnt;  // (MODE 2: the word IS the count)
+                        double val = AF ? (double)(i64)a_keep[e] * a.af_scale : (double)count;  // exact: < 2^53 units, power-of-two scale
                         if (a.weights) val *= a.weights[a.first + s[e]];
-                        const AfCand cand{val, c_keep[e], s[e], i0 + e * UTM_LOOP_THREADS};
+                        const AfCand cand{val, count, s[e], i0 + e * UTM_LOOP_THREADS};
                         if (better_af(cand, fbest)) fbest = cand;
                     }
                     need &= ~((fin ? 1u : 0u) << e);
@@ -260,7 +265,7 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            if (!AF) {
+            if (!DBL) {
                 IntCand other;
                 other.cnt = __shfl_xor(best.cnt, o, 64);
                 other.s = __shfl_xor(best.s, o, 64);
@@ -279,10 +284,10 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
         if (threadIdx.x == 0) L->failed = 0;
         if (threadIdx.x == 0) UTM_LSTAMP(sync, k, 0);
         __syncthreads();
-        if (AF) best = IntCand{fbest.cnt, fbest.s, fbest.pos};
+        if (DBL) best = IntCand{fbest.cnt, fbest.s, fbest.pos};
         if (lane == 0) {
             L->wbest[threadIdx.x >> 6] = best;
-            if (AF) L->wval[threadIdx.x >> 6] = fbest.val;
+            if (DBL) L->wval[threadIdx.x >> 6] = fbest.val;
         }
         if (failed) L->failed = 1;
         __syncthreads();
@@ -296,9 +301,9 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                 stop = 1;
                 loop_publish(sync, epoch, 1, 0, 0, 0, 0);
             } else {
-                double best_val = AF ? fbest.val : 0.0;
+                double best_val = DBL ? fbest.val : 0.0;
                 for (int w8 = 1; w8 < UTM_LOOP_WAVES; ++w8) {
-                    if (!AF) {
+                    if (!DBL) {
                         if (better_int(L->wbest[w8], best)) best = L->wbest[w8];
                     } else {
                         const AfCand o{L->wval[w8], L->wbest[w8].cnt, L->wbest[w8].s, L->wbest[w8].pos};
@@ -309,11 +314,11 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                         }
                     }
                 }
-                if (!AF) best_val = (double)best.cnt;
+                if (!DBL) best_val = (double)best.cnt;
                 // decide_single, on the loop state this thread carries in registers (a negative best score only wins when
                 // no sample holds a masked 0: select.py:43-48)
                 const bool zero_elsewhere = n_active_total < (i64)a.n_total;
-                if (n_active == 0 || (AF ? (best_val == 0.0 || (best_val < 0.0 && zero_elsewhere)) : best.cnt == 0)) {
+                if (n_active == 0 || (DBL ? (best_val == 0.0 || (best_val < 0.0 && zero_elsewhere)) : best.cnt == 0)) {
                     st->done = 1;  // (None, None): no row (select.py:51-52, :93-96)
                     a.res_idx[iter] = -1;
                     stop = 1;
@@ -433,7 +438,10 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
     constexpr unsigned TILE_WORDS = STEPS * UTM_STEP_WORDS;
     const unsigned n_tiles = (unsigned)((wp + TILE_WORDS - 1) / TILE_WORDS);
     if (blockIdx.x == 0) {
-        loop_picker<AF>(pa, sync, cnt0, cnt1, laf.afd0, laf.afd1, claim, n_tiles, gridDim.x, k_batch, reinterpret_cast<LoopPickLds *>(&live[0]));
+        LoopPickLds *lds = reinterpret_cast<LoopPickLds *>(&live[0]);
+        if (AF) loop_picker<1>(pa, sync, cnt0, cnt1, laf.afd0, laf.afd1, claim, n_tiles, gridDim.x, k_batch, lds);
+        else if (pa.weights) loop_picker<2>(pa, sync, cnt0, cnt1, nullptr, nullptr, claim, n_tiles, gridDim.x, k_batch, lds);
+        else loop_picker<0>(pa, sync, cnt0, cnt1, nullptr, nullptr, claim, n_tiles, gridDim.x, k_batch, lds);
         return;
     }
     if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync->arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
