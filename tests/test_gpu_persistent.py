@@ -236,3 +236,22 @@ def test_persistent_loop_with_weights(dev, kind):
         st = m.stats()
     assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
     assert st["persist_iterations"] == st["iterations"] or len(exp[0]) == 0
+
+
+def test_a_grid_that_cannot_be_resident_aborts_at_its_census_and_the_launches_take_over(dev, monkeypatch):
+    """UTM_PERSIST_WGS_PER_CU far beyond what a CU holds: the blocks that do become resident count in, the picker's bounded
+    census wait runs out, everybody leaves without having touched anything (xerror 3), and the context runs the same batch
+    -- and everything after it -- as one launch per iteration.  Same rows; no persistent iteration on record."""
+    monkeypatch.setenv("UTM_PERSIST_WGS_PER_CU", "12")
+    rng = np.random.default_rng(21)
+    dense = ou.random_dense(rng, 200_000, 2_000, density=0.01)
+    st = run_both(dev, dense, k=40)
+    assert st["persist_iterations"] == 0 and st["persist_launches"] == 0 and st["score_launches"] >= 40
+
+
+def test_a_batch_longer_than_a_launch_holds_is_cut(dev, monkeypatch):
+    monkeypatch.setenv("UTM_BATCH", "1000")
+    rng = np.random.default_rng(22)
+    dense = ou.random_dense(rng, 20_000, 700, density=0.01)
+    st = run_both(dev, dense)
+    assert st["persist_iterations"] == st["iterations"] and st["persist_launches"] >= 3

@@ -598,7 +598,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
                                : (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, c->iter < 8 ? 4 : 8)
                                : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, decr_first)
                                                                                             : batch;
-        const i64 n = std::min<i64>(this_batch, k_max - enq);
+        i64 n = std::min<i64>(this_batch, k_max - enq);
         const unsigned a0 = c->active_ub;
         // Decremental batches: only when allowed, when the persistent counts are current, and when the last
         // winner newly covered few enough variants (gains shrink over a greedy run, so it stays that way).
@@ -619,6 +619,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // short scans (and any matrix whose tile grid fits the resident blocks): the whole batch as ONE persistent launch
         const bool loop_af = af_par && loop_af_ready(c, first_is_full);
         const LoopShape loop = (!decr && fuse_mode == 1 && c->tune.fuse_pick && (c->af_mode == UTM_AF_NONE || loop_af)) ? loop_shape(c, loop_af) : LoopShape();
+        if (loop.ok) n = std::min<i64>(n, 256);  // (a launch's record carries an 8-bit iteration tag; UTM_BATCH may ask for more)
         if (loop.ok) TRY(enqueue_loop(c, loop, (int)n, loop_af));
         for (i64 j = 0; j < n && !loop.ok; ++j) {
             bool picked = false;
