@@ -194,6 +194,10 @@ static LoopShape loop_shape(utm_ctx *c, bool af = false)
         if (tn.persist_tile_kib > 0 && steps != tn.persist_tile_kib) continue;
         const u64 tiles = (steps_total + steps - 1) / steps;
         if (tiles > (u64)std::max(1, tn.persist_max_tiles) && tn.persist_tile_kib <= 0) continue;
+        // tiles of several batches only pay where the launch per iteration is weak -- few samples, tall columns (10M x 313:
+        // +12 %); with 2,504 samples they lose ~10 % to the one-batch tile at equal height (1.1M: 0.70 against 0.79) and
+        // are level with the launches at best (3M: +2 % / -3.4 %)
+        if (steps > 8 && tn.persist_tile_kib <= 0 && c->n_local > (unsigned)std::max(0, tn.persist_tall_max_samples)) break;
         int per_cu = std::min(occ[t], 2048 / UTM_LOOP_THREADS);
         if (tn.persist_wgs_per_cu > 0) per_cu = tn.persist_wgs_per_cu;  // (an override, also upwards: the census decides whether the grid is resident)
         const u64 max_workers = (u64)cus * (u64)std::max(per_cu, 0);

@@ -126,7 +126,7 @@ struct Tune {
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
-    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, persist_af, test_drop_arrival;
+    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, persist_tall_max_samples, persist_af, test_drop_arrival;
     int mbox_spins_log2, test_mute_exchange;                                 // mailbox exchange: patience, test hook   // persistent loop kernel
 };
 struct KnobDef {
@@ -164,6 +164,7 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_PERSIST_WGS_PER_CU", persist_wgs_per_cu, 0),
     UTM_KNOB_I("UTM_PERSIST_MAX_TILES", persist_max_tiles, 32),
     UTM_KNOB_I("UTM_PERSIST_TILE_KIB", persist_tile_kib, 0),
+    UTM_KNOB_I("UTM_PERSIST_TALL_MAX_SAMPLES", persist_tall_max_samples, 640),  // tiles of several batches (columns taller than 32 x 8 KiB) only up to this many samples
     UTM_KNOB_I("UTM_PERSIST_MAX_SAMPLES", persist_max_samples, 2560),  // (one chunk of count words for the picker: UTM_LOOP_THREADS x UTM_LOOP_E)
     UTM_KNOB_I("UTM_PERSIST_AF", persist_af, 1),  // the AF form (exact float32 phase) of the persistent loop
     UTM_KNOB_I("UTM_PERSIST_CLAIMS", persist_claims, 1),
