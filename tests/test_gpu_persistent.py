@@ -255,3 +255,28 @@ def test_a_batch_longer_than_a_launch_holds_is_cut(dev, monkeypatch):
     dense = ou.random_dense(rng, 20_000, 700, density=0.01)
     st = run_both(dev, dense)
     assert st["persist_iterations"] == st["iterations"] and st["persist_launches"] >= 3
+
+
+@pytest.mark.parametrize("af", [False, True])
+def test_persistent_loop_with_more_samples_than_one_picker_chunk(dev, af, monkeypatch):
+    """UTM_PERSIST_MAX_SAMPLES=0 lifts the default limit of 2,560 samples: the picker then walks the count words in
+    several chunks (and re-reads act[] and the AF accumulators per chunk) -- slower, same rows."""
+    monkeypatch.setenv("UTM_PERSIST_MAX_SAMPLES", "0")
+    rng = np.random.default_rng(31 + af)
+    n_var, n_samp = 30_000, 6_000
+    dense = ou.random_dense(rng, n_var, n_samp, density=0.004)
+    cols = npo.pack_columns(dense)
+    state = np.ones(n_samp, np.uint8)
+    state[rng.choice(n_samp, 300, replace=False)] = 2
+    afv = (rng.integers(1, 2 * n_samp, n_var) / (2.0 * n_samp)).astype(np.float32) if af else None
+    exp = ou.c_greedy(cols, n_var, state, None, afv, k_max=150)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols)
+        if af:
+            m.set_af(c, afv)
+        m.set_state(state)
+        got = m.run(150)
+        st = m.stats()
+    assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
+    assert st["persist_iterations"] > 0
