@@ -73,6 +73,9 @@ static_assert(sizeof(LoopSync) % 16 == 0, "zeroed by one memset");
 // AF form: a count word = decrease:40 | partials arrived:12 | non-empty partials among them:12; a sum word = decrease:56 |
 // non-empty partials arrived:8 (at most 64 tiles; a decrease stays below 2^53 units) -- the picker takes a position when
 // the first shows all tiles and the second shows as many arrivals as the first announces
+#ifndef UTM_AF_GATHER_ON
+#define UTM_AF_GATHER_ON 1  // (0: a timing experiment only -- wrong sums -- that prices the AF form's gathers)
+#endif
 #define UTM_NONEMPTY_SHIFT 52
 #define UTM_AFD_ARRIVAL_SHIFT 56
 #define UTM_COLS_SLACK_BYTES (64u << 10)  // zeros behind a chunk's last column (whole-batch reads of a short last tile)
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
                 nb_ += __popc(X[q].x) + __popc(X[q].y) + __popc(X[q].z) + __popc(X[q].w);            \
             }                                                                                        \
             acc += nb_;                                                                              \
-            if (__ballot(nb_ != 0) != 0) { /* rare once coverage has grown: walk the surviving bits */ \
+            if (UTM_AF_GATHER_ON && __ballot(nb_ != 0) != 0) { /* rare once coverage has grown: walk the surviving bits */ \
                 const unsigned *af_ = laf.afbits + (w0 + (u64)(J) * 8 * UTM_STEP_WORDS + 2 * lane) * 64; \
                 _Pragma("unroll") for (int q = 0; q < U; ++q)                                        \
                 {                                                                                    \
