@@ -1,33 +1,38 @@
-// The integer greedy loop as ONE persistent launch per batch of iterations (DESIGN.md section 4
-// "Persistent loop").  Replaces, for unweighted integer scores on one chunk, the per-iteration k_score_int<.., FUSED>
-// launches: the per-iteration fixed costs of a launch (dispatch ramp, the tail after the last scoring wave, the kernel
-// boundary: 4-5 us of a 30 us iteration at 1.1M x 2,504) are what keeps short scans off the HBM roofline.
+// The greedy loop as ONE persistent launch per batch of up to 256 iterations (DESIGN.md section 4 "The
+// loop as ONE launch per batch of iterations").  Replaces, for integer scores (weighted or not) and the exact phase of
+// float32 AF on one chunk / one shard, the per-iteration k_score_* launches: the per-iteration fixed costs of a launch
+// (dispatch ramp, the tail after the last scoring wave, the kernel boundary: 4-5 us of a 30 us iteration at 1.1M x 2,504)
+// are what keeps short scans off the HBM roofline.  (select.py:91-112 is the loop this runs; :24-53 one iteration.)
 //
-// Roles.  Block 0 is the PICKER (mask / argmax / decide, select.py:43-53 and :93-112, as fused_pick does).  Every
-// other block is a WORKER that owns ONE variant tile for the whole launch and one of Q slots of it; its four waves own
-// the positions  i = 4*slot + wave + 4*Q*m  of act[] (strided, so the shares stay even while the selectable set
-// shrinks).  A worker stages ~covered for its tile in LDS ONCE, at the start of the launch; from then on an iteration
-// costs it one winner-tile read (`live &= ~winner`), never a covered read: the covered mask lives in the workers' LDS
-// and goes back to memory when the launch ends.
+// Roles.  Block 0 is the PICKER (mask / weights / argmax / decide, select.py:43-53 and :93-112, as fused_pick does).  Every
+// other block (512 threads) is a WORKER that owns ONE variant tile (1, 2, 4 or 8 batches of 8 KiB) for the whole launch and
+// one of Q slots of it; a tile's workers are spread over all XCDs and dispatch ages (tile = worker % tiles).  A worker
+// stages ~covered for its tile in LDS ONCE, at the start of the launch; from then on an iteration costs it one winner-tile
+// read (`live &= ~winner`), never a covered read: the covered mask lives in the workers' LDS and goes back to memory when
+// the launch ends.
 //
-// One iteration.  Workers stream their columns through the tile exactly like k_score_int (16-byte loads, 1 KiB per
-// wave instruction, 8 in flight) and add every (position, tile) partial to the position's count word as
+// One iteration.  A wave's work is a stream of 8 KiB batches, two in flight (x0 / x1): the batches of its two static
+// positions of act[] (first = 8*slot + wave, second = first + 8Q), then of positions it CLAIMS, one ticket at a time, from
+// the tile's eight counters (three counter sets in turn, iteration % 3, so that an iteration's first two tickets can be
+// taken while the one before still runs).  Every (position, tile) partial is added to the position's count word as
 // `count + 2^40` (self-certifying words: the picker polls them until bits 40.. show all tiles; nobody signals).  The
 // picker reduces, decides, and PUBLISHES the iteration in two tagged 8-byte words (sc1 stores):
 //     W0 = epoch:24 | stop:1 | removed:1 | winner's local column:38      W1 = epoch:8 | best_pos:28 | moved sample:28
-// (`moved` = the sample swap-removed into the winner's position of act[]).  Workers poll W0/W1 (one wave per
-// workgroup), AND the winner's tile out of their LDS tile, patch their copy of act[] from the record and go on.
+// (`moved` = the sample swap-removed into the winner's position of act[]).  Workers poll W0/W1 (one wave per workgroup),
+// AND the winner's tile out of their LDS tile, patch their view of act[] from the record and go on.
 //
-// What hides the hand-off: while a wave waits for the record it already holds the first 8 KiB of its next iteration in
-// registers -- the sample at its first position is the one it had (unless the record says that very position changed,
-// then it reloads) and column data never changes -- so the memory pipes stay full across the picker's critical path.
+// What hides the hand-off: while a wave waits for the record it holds the first two batches of its next iteration in
+// registers -- the samples at its static positions are the ones it had (unless the record names those very positions,
+// then they are loaded again) and column data never changes.  The first goes out as soon as the wave runs dry (it fills
+// the iteration's tail), the second is held back until ~4 us before the record is due by the wave's own clock (iterations
+// shrink smoothly), so that it is in flight while the picker reduces and the tile is updated.
 //
 // Visibility (MI355X_MICROARCH.md, inter-workgroup visibility).  Everything that crosses workgroups inside the launch
 // is an agent-scope atomic or an sc1 access on both sides: count words (atomic add / atomic load / atomic store),
 // the record (atomic store / atomic load, tags in both words: a torn pair is re-read), act[] (the picker's atomic
-// store; workers' atomic loads, patched with the newest record because that store may still be in flight), census
-// counters.  Columns are immutable.  Count words alternate between two buffers by iteration parity, so the picker's
-// clearing stores have a whole iteration to land before the words are added to again.
+// store; workers' atomic loads, patched with the newest record because that store may still be in flight), claim and
+// census counters.  Columns are immutable.  Count words alternate between two buffers by iteration parity, so the
+// picker's clearing stores have a whole iteration to land before the words are added to again.
 //
 // AF form (template parameter AF, below): the exact float32-AF phase as delta iterations on per-sample accumulators -- a
 // second LDS tile holds what the pending winner newly covers, the words carry decreases.
@@ -50,8 +55,8 @@ struct LoopSync {
     unsigned pad1[30];
 #ifdef UTM_DEBUG_STAMPS
     // per iteration of the launch (s_memrealtime, 10 ns ticks): 0 picker saw every count word complete, 1 record published,
-    // 2 block 1 / wave 0 finished its positions, 3 ... saw the record, 4 ... tile updated, 5 latest partial count of any
-    // wave (atomic max), 6 block 1 / wave 0 first batch of the next iteration counted
+    // 2 block 1 / wave 0 finished its positions, 3 ... saw the record, 4 ... tile updated, 5 unused, 6 block 1 / wave 0 first
+    // batch of the next iteration counted
     u64 stamps[256][8];
     u64 wave_t[2][8192];  // iteration UTM_STAMP_ITER of the launch: every wave's [0] tile-ready and [1] last-partial times
 #endif
@@ -400,15 +405,16 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
 }
 
 // ------------------------------------------------------------------------------------------------ the launch
-// Grid = 1 + n_tiles * Q blocks of 256 threads: block 0 picks; worker w = blockIdx.x - 1 owns tile w % n_tiles, slot
+// Grid = 1 + n_tiles * Q blocks of 512 threads: block 0 picks; worker w = blockIdx.x - 1 owns tile w % n_tiles, slot
 // w / n_tiles -- a tile's workers are spread over all XCDs and over all dispatch ages (measured: a CU serves its oldest
 // waves first and the XCDs differ by up to 18 % in speed, so statically equal shares finished up to a third of an
-// iteration apart).  Positions: every wave has ONE static position, first = 4 * slot + wave (< 4Q: the one it holds
-// data for across the hand-off); the positions from 4Q on are CLAIMED, one at a time, from the tile's four counters
-// (one per wave index: position = 4Q + 4 * ticket + wave), so fast waves take more and a tile's waves finish together.
-// A claim is issued before the column loads of the position in front of it, so its round trip hides behind them; a
-// wave issues no claim after the one that came back out of range, and waits for every claim before its last partial
-// count -- which is why the picker may reset an iteration's counters as soon as all its count words are complete.
+// iteration apart).  Positions: every wave has TWO static positions, first = 8 * slot + wave and second = first + 8Q (the
+// ones whose first batches it holds across the hand-off); the positions from 16Q on are CLAIMED, one at a time, from the
+// tile's eight counters (one per wave index: position = 16Q + 8 * ticket + wave), so fast waves take more and a tile's
+// waves finish together.  A claim is issued ahead of the column loads of the batch in front of it, so its round trip
+// hides behind them; a wave issues no claim after the one that came back out of range, and has every claim back before its
+// last partial count goes out -- which is why the picker may reset an iteration's counters as soon as all its count
+// words are complete.
 // drop_iter: test hook (0 = off) -- the first worker withholds one partial count in that iteration of the launch, so
 // that the picker's bounded wait runs out.
 // AF: the delta form of the exact fixed-point AF phase.  The per-sample accumulators (count, fixed-point sum) are valid
