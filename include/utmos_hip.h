@@ -123,9 +123,10 @@ typedef struct utm_stats {
     /* allele-frequency scoring, verified-parallel form, since the last utm_reset: */
     int64_t af_chained_iterations; /* iterations whose pick needed sequential float64 chains on the spot (near-ties) */
     int64_t af_deferred_rows;      /* rows whose exact float64 score was finished after their batch (one launch set per batch) */
-    /* persistent loop (unweighted integer scores, one chunk, the only shard): batches of iterations run as ONE launch */
+    /* persistent loop (one chunk, the only shard; integer scores and the verified-parallel AF forms): batches of iterations run as ONE launch */
     int64_t persist_launches;      /* such launches since the last utm_reset (each counts once in score_launches) */
     int64_t persist_iterations;    /* rows they produced (0: every iteration was a launch of its own) */
+    int64_t persist_unresolved;    /* launches (interval form of the AF loop) that left their last iteration to a verification launch */
 } utm_stats;
 
 /* utm_stats.exchange */

@@ -193,12 +193,13 @@ def test_persistent_af_loop_exact_phase(dev, n_var, n_samp, weights):
         assert st["persist_iterations"] > 0.5 * len(idx), st    # most of the run went through k_loop_int<.., AF>
 
 
-def test_persistent_af_loop_can_be_switched_off_and_float64_af_keeps_the_launches(dev, monkeypatch):
+def test_persistent_af_loop_can_be_switched_off(dev, monkeypatch):
+    """(UTM_PERSIST_AF=0 switches off both AF forms: float64 AF takes the interval form, tests/test_gpu_persistent_interval.py)"""
     rng = np.random.default_rng(77)
     dense, af = _af_case(rng, 50_000, 200)
     cols = npo.pack_columns(dense)
     state = np.ones(200, np.uint8)
-    for af_values, env, expect in ((af, "1", True), (af, "0", False), (af.astype(np.float64) / 3.0, "1", False)):
+    for af_values, env, expect in ((af, "1", True), (af, "0", False), (af.astype(np.float64) / 3.0, "1", True), (af.astype(np.float64) / 3.0, "0", False)):
         monkeypatch.setenv("UTM_PERSIST_AF", env)
         exp = ou.c_greedy(cols, 50_000, state, None, af_values)
         with dev.DeviceMatrix(200) as m:

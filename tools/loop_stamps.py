@@ -18,7 +18,7 @@ m = device.DeviceMatrix(n_samp)
 c = m.add_chunk(n_var)
 m.synth_fill(c, seed=0)
 m.reset()
-out = (ctypes.c_uint64 * (256 * 8))()
+out = (ctypes.c_uint64 * (256 * 16))()
 wt = (ctypes.c_uint64 * (2 * 8192))()
 done = 0
 while done < n_samp:
@@ -27,7 +27,7 @@ while done < n_samp:
     if n == 0:
         break
     lib.utm_dbg_loop_stamps(m._h, out, wt)
-    t = np.array(list(out), dtype=np.float64).reshape(256, 8)[:n - 1] * 0.01       # us; the last iteration of a launch has no successor
+    t = np.array(list(out), dtype=np.float64).reshape(256, 16)[:n - 1] * 0.01       # us; the last iteration of a launch has no successor
     w = np.array(list(wt), dtype=np.float64).reshape(2, 8192) * 0.01
     if len(t) > 4:
         pub = t[:, 1]
@@ -46,5 +46,5 @@ while done < n_samp:
         print(line)
         if done == 0 and n > 101:
             np.save(os.path.join(root, "gpurun_out", f"loop_wave_t_{n_var}.npy"), np.array(list(wt), dtype=np.uint64).reshape(2, 8192))
-            np.save(os.path.join(root, "gpurun_out", f"loop_stamps_{n_var}.npy"), np.array(list(out), dtype=np.uint64).reshape(256, 8))
+            np.save(os.path.join(root, "gpurun_out", f"loop_stamps_{n_var}.npy"), np.array(list(out), dtype=np.uint64).reshape(256, 16))
     done += n

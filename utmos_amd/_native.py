@@ -36,7 +36,8 @@ class Stats(ctypes.Structure):
                 ("p2p_replica_bytes", ctypes.c_int64), ("decr_interleaved_bytes", ctypes.c_int64),
                 ("exchange", ctypes.c_int32), ("rccl_ranks", ctypes.c_int32),
                 ("af_chained_iterations", ctypes.c_int64), ("af_deferred_rows", ctypes.c_int64),
-                ("persist_launches", ctypes.c_int64), ("persist_iterations", ctypes.c_int64)]
+                ("persist_launches", ctypes.c_int64), ("persist_iterations", ctypes.c_int64),
+                ("persist_unresolved", ctypes.c_int64)]
 
 
 EXCHANGE_NAMES = {0: "none", 1: "mailboxes", 2: "rccl", 3: "caller-driven", 4: "rccl-allreduce"}

@@ -18,11 +18,10 @@
 // ------------------------------------------------------------------------------------------------
 // est_exact: the ESTIMATE is the reference's sum (what IterState::all_exact is about); exact: the value returned in
 // `est` is -- the estimate, or a sum a chain produced earlier for this very count (PickArgs::known_*).
-__device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c, double &lo, double &hi, double &est,
-                                            bool &exact, bool &est_exact)
+// (the accumulators and the record passed in: the persistent loop's picker keeps them in registers, loop_int.hip.h)
+__device__ __forceinline__ void af_interval_regs(const PickArgs &a, unsigned s, u64 c, i64 e, u64 on_record, double rec_val, double &lo, double &hi,
+                                                 double &est, bool &exact, bool &est_exact)
 {
-    const u64 on_record = a.known_cnt ? a.known_cnt[s] : ~0ull;  // (requested together with the sum, not behind it)
-    const i64 e = a.afsum[s];
     est = (double)e * a.af_scale;
     const double top = a.af_trunc ? est + (double)c * a.af_scale : est;  // upper end of the exact float32 sum
     double rel;
@@ -35,7 +34,7 @@ __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c
     }
     est_exact = exact;
     if (!exact && on_record == c) {
-        est = a.known_val[s];
+        est = rec_val;
         exact = true;
     }
     double l = exact ? est : est - rel * est, h = exact ? est : top + rel * top;
@@ -48,6 +47,13 @@ __device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c
     }
     lo = l;
     hi = h;
+}
+__device__ __forceinline__ void af_interval(const PickArgs &a, unsigned s, u64 c, double &lo, double &hi, double &est,
+                                            bool &exact, bool &est_exact)
+{
+    const u64 on_record = a.known_cnt ? a.known_cnt[s] : ~0ull;  // (requested together with the sum, not behind it)
+    const double rec_val = (a.known_cnt && on_record == c) ? a.known_val[s] : 0.0;
+    af_interval_regs(a, s, c, a.afsum[s], on_record, rec_val, lo, hi, est, exact, est_exact);
 }
 
 // Candidates of the iteration (see above) by ONE workgroup of 256 or 1024 threads; returns (to every thread) whether

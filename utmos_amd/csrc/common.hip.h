@@ -37,7 +37,7 @@ struct IterState {
     // decremental scoring: work actually done (for the byte accounting)
     u64 xseq;           // mailbox exchanges completed (identical on every shard)
     int xerror;         // a peer's record did not arrive in time
-    int pad_;
+    int loop_unresolved;  // a persistent launch (interval form) ended with an iteration scored but not decided (loop_int.hip.h)
     u64 decr_entries;   // sum over decremental iterations of the newly-covered word count
     u64 decr_gathers;   // ... of (selectable samples x newly-covered words)
     // AF delta passes: sum of the selectable samples' counts (k_count_sum) -- its decrease between two readings, minus

@@ -154,36 +154,47 @@ struct LoopShape {
     int steps = 8;
     unsigned q_slots = 0, n_tiles = 0;
 };
-// af: the caller has established the AF form's preconditions (loop_af_ready); otherwise AF runs keep the launches.
-// (Weighted integer scores take the loop too: the picker compares float64 products.)
-static LoopShape loop_shape(utm_ctx *c, bool af = false)
+// af: the caller has established an AF form's preconditions (loop_af_form: 1 exact, 2 intervals); otherwise AF runs keep
+// the launches.  (Weighted integer scores take the loop too: the picker compares float64 products.)
+static int loop_chainers(const utm_ctx *c)
+{
+    return std::min(UTM_LOOP_MAX_CHAINERS, std::max(1, c->tune.persist_chainers));
+}
+static LoopShape loop_shape(utm_ctx *c, int af = 0)
 {
     LoopShape sh;
     const Tune &tn = c->tune;
+    // (interval form: the picker keeps every selectable sample's accumulators and record in registers -- one chunk of words)
+    if (af == 2 && c->n_local > (unsigned)(UTM_LOOP_THREADS * UTM_LOOP_E)) return sh;
     if (!tn.persistent || c->persist_off || (!af && c->af_mode != UTM_AF_NONE) || c->decr_enabled || c->chunks.size() != 1 ||
         c->n_ranks != 1 || c->n_local != c->n_total || c->comm || c->p2p || c->n_local >= UTM_LOOP_MAX_LOCAL ||
         (tn.persist_max_samples > 0 && c->n_local > (unsigned)tn.persist_max_samples))
         return sh;
     const Chunk &ch = c->chunks[0];
     if (tn.persist_max_mb > 0 && (u64)c->n_local * ch.wp * 8 > ((u64)tn.persist_max_mb << 20)) return sh;
-    static int cus = 0, occ_all[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // resident blocks per CU for the 8 / 16 / 32 / 64 KiB tile, integer / AF form
+    static int cus = 0, occ_all[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};  // resident blocks per CU for the 8 / 16 / 32 / 64 KiB tile, integer / AF / AF-interval form
     if (!cus) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return sh;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][0], k_loop_int<8, true, false>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][1], k_loop_int<16, true, false>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][2], k_loop_int<32, true, false>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][3], k_loop_int<64, true, false>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][0], k_loop_int<8, true, true>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][1], k_loop_int<16, true, true>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][2], k_loop_int<32, true, true>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][3], k_loop_int<64, true, true>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][0], k_loop_int<8, true, 0>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][1], k_loop_int<16, true, 0>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][2], k_loop_int<32, true, 0>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[0][3], k_loop_int<64, true, 0>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][0], k_loop_int<8, true, 1>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][1], k_loop_int<16, true, 1>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][2], k_loop_int<32, true, 1>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][3], k_loop_int<64, true, 1>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[2][0], k_loop_int<8, true, 2>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[2][1], k_loop_int<16, true, 2>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[2][2], k_loop_int<32, true, 2>, UTM_LOOP_THREADS, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[2][3], k_loop_int<64, true, 2>, UTM_LOOP_THREADS, 0);
         cus = prop.multiProcessorCount;
         if (getenv("UTM_VERBOSE"))
-            fprintf(stderr, "libutmos_hip: k_loop_int occupancy query: %d / %d / %d / %d (AF form %d / %d / %d / %d) blocks of %d threads per CU (8 / 16 / 32 / 64 KiB tile), %d CUs\n",
-                    occ_all[0][0], occ_all[0][1], occ_all[0][2], occ_all[0][3], occ_all[1][0], occ_all[1][1], occ_all[1][2], occ_all[1][3], UTM_LOOP_THREADS, cus);
+            fprintf(stderr, "libutmos_hip: k_loop_int occupancy query: %d / %d / %d / %d (AF form %d / %d / %d / %d, with intervals %d / %d / %d / %d) blocks of %d threads per CU (8 / 16 / 32 / 64 KiB tile), %d CUs\n",
+                    occ_all[0][0], occ_all[0][1], occ_all[0][2], occ_all[0][3], occ_all[1][0], occ_all[1][1], occ_all[1][2], occ_all[1][3],
+                    occ_all[2][0], occ_all[2][1], occ_all[2][2], occ_all[2][3], UTM_LOOP_THREADS, cus);
     }
-    const int *occ = occ_all[af ? 1 : 0];
+    const int *occ = occ_all[af];
     // Tile: the smallest of 8 / 16 / 32 / 64 KiB that cuts a column into at most persist_max_tiles tiles -- every (position,
     // tile) pair costs one atomic on the position's count word, 16 count words share a cache line, and beyond ~30 tiles
     // those lines become the bottleneck (measured: 2,504 samples, 31 tiles +3.5 %, 39 tiles -2 %, 153 tiles -15 % against
@@ -201,8 +212,9 @@ static LoopShape loop_shape(utm_ctx *c, bool af = false)
         int per_cu = std::min(occ[t], 2048 / UTM_LOOP_THREADS);
         if (tn.persist_wgs_per_cu > 0) per_cu = tn.persist_wgs_per_cu;  // (an override, also upwards: the census decides whether the grid is resident)
         const u64 max_workers = (u64)cus * (u64)std::max(per_cu, 0);
-        if (max_workers < 16 || tiles > max_workers - 1) continue;
-        const u64 q = (max_workers - 1) / tiles;  // (the picker's block comes out of the same budget)
+        const u64 others = af == 2 ? 1 + (u64)loop_chainers(c) : 1;  // the picker's block (and the interval form's chainers) come out of the same budget
+        if (max_workers < 16 || tiles > max_workers - others) continue;
+        const u64 q = (max_workers - others) / tiles;
         sh.ok = true;
         sh.steps = steps;
         sh.n_tiles = (unsigned)tiles;
@@ -217,13 +229,22 @@ static LoopShape loop_shape(utm_ctx *c, bool af = false)
 // selectable sample's sum below 2^53 units (latched from the device: af_all_exact -- the plain exact pick suffices, no
 // candidates, no chains, no deferred scores), the per-sample accumulators valid, and the pending winner no longer covering
 // percents of all variants (those first delta passes gather from LDS in k_score_afq; here a gather is a global load).
-static bool loop_af_ready(const utm_ctx *c, bool first_is_full)
+// The interval form (2) takes the other verified-parallel AF runs -- float64 AF values, or float32 sums that are not
+// (yet) all exact: candidates and their chains inside the picker (loop_picker<3>), as long as a lone candidate needs no
+// chain of its own (its exact score is deferred, or not wanted: PickArgs::af_skip_single).  -> 0 (the launches), 1, 2.
+static int loop_af_form(const utm_ctx *c, bool first_is_full)
 {
-    return c->tune.persist_af && c->af_mode == UTM_AF_F32 && c->af_fixed && !c->af_trunc && c->af_all_exact && c->keep_valid && !first_is_full &&
-           c->last_new >= 0 && (double)c->last_new <= c->tune.af_dense_delta * (double)c->n_var_total;
+    if (c->persist_backoff > 0) return 0;  // (launches of the interval form kept ending undecided: some iterations as launches first)
+    if (c->af_mode == UTM_AF_NONE || !c->af_fixed || !c->keep_valid || first_is_full || c->last_new < 0 ||
+        (double)c->last_new > c->tune.af_dense_delta * (double)c->n_var_total)
+        return 0;
+    if (c->af_mode == UTM_AF_F32 && !c->af_trunc && c->af_all_exact) return c->tune.persist_af ? 1 : 0;
+    if (c->af_all_exact) return 0;
+    const bool skip_single = (!c->af_exact_scores || defer_active(c)) && c->n_local == c->n_total;
+    return (c->tune.persist_af && c->tune.persist_af_interval && c->tune.af_record && skip_single) ? 2 : 0;  // (the sums on record are how the chainer answers)
 }
 
-static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch, bool af = false)
+static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch, int af = 0)
 {
     const Chunk &ch = c->chunks[0];
     if (af && !c->d_loop_w[0]) {  // the AF form's per-position words: two arrival / count-decrease words, two sum-decrease words
@@ -246,17 +267,34 @@ static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch, bool af = 
     HIP_TRY(hipMemsetAsync(c->d_claim, 0, claim_bytes, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_loop_sync, 0, sizeof(LoopSync), c->stream));
     const PickArgs pa = pick_args(c);
-    const dim3 grid(sh.n_tiles * sh.q_slots + 1);
+    const int n_chainers = af == 2 ? loop_chainers(c) : 0;
+    if (af == 2 && c->loop_priv_words < (size_t)n_chainers * ch.wp) {  // the chainers' covered masks
+        (void)hipFree(c->d_loop_priv);
+        c->d_loop_priv = nullptr;
+        c->loop_priv_words = 0;
+        HIP_TRY(hipMalloc(&c->d_loop_priv, (size_t)n_chainers * ch.wp * 8));
+        c->loop_priv_words = (size_t)n_chainers * ch.wp;
+    }
+    const dim3 grid(sh.n_tiles * sh.q_slots + 1 + n_chainers);  // picker + workers (+ chainers)
     const int drop = c->tune.test_drop_arrival;
     LaunchTimer t(c);
-    const LoopAf laf{af ? ch.afx : nullptr, af ? c->d_loop_w[2] : nullptr, af ? c->d_loop_w[3] : nullptr};
+    const LoopAf laf{af ? ch.afx : nullptr, af ? c->d_loop_w[2] : nullptr, af ? c->d_loop_w[3] : nullptr,
+                     af == 2 ? ch.af : nullptr, af == 2 ? c->d_loop_priv : nullptr,
+                     (af == 2 && defer_active(c)) ? c->d_newly_log + ch.off : nullptr, c->col_words, c->tune.persist_spec_ticks, n_chainers};
     u64 *w0 = af ? c->d_loop_w[0] : c->d_cnt, *w1 = af ? c->d_loop_w[1] : c->d_cnt_alt;  // (AF: d_cnt holds the per-sample counts)
+    if (getenv("UTM_VERBOSE") && c->persist_launches == 0)
+        fprintf(stderr, "libutmos_hip: k_loop_int form %d: cols %p..%p covered %p priv %p (wp %llu) af %p afx %p log %p (stride %llu) known %p %p words %p %p %p %p act %p cnt %p afsum %p sync %p claim %p grid %u\n",
+                af, (void *)ch.cols, (void *)(ch.cols + (size_t)c->n_local * ch.wp), (void *)ch.covered, (void *)c->d_loop_priv, (unsigned long long)ch.wp,
+                (void *)ch.af, (void *)ch.afx, (void *)laf.newly_log, (unsigned long long)c->col_words, (void *)c->d_known_cnt, (void *)c->d_known_val,
+                (void *)c->d_loop_w[0], (void *)c->d_loop_w[1], (void *)c->d_loop_w[2], (void *)c->d_loop_w[3], (void *)c->d_act, (void *)c->d_cnt,
+                (void *)c->d_afsum, (void *)c->d_loop_sync, (void *)c->d_claim, grid.x);
 #define UTM_LAUNCH_LOOP(S, NT, AFF)                                                                                                 \
     UTM_TIMED_LAUNCH(t, (k_loop_int<S, NT, AFF>), grid, dim3(UTM_LOOP_THREADS), (const u64 *)ch.cols, ch.covered, ch.wp, pending_of(c, ch, true), c->d_st, \
                      c->d_act, w0, w1, sh.q_slots, c->d_claim, k_batch, c->d_loop_sync, pa, drop, c->tune.persist_claims, c->tune.persist_ahead_ticks, c->tune.persist_ahead0_ticks, laf)
 #define UTM_LAUNCH_LOOP2(S, NT) \
-    if (af) UTM_LAUNCH_LOOP(S, NT, true); \
-    else UTM_LAUNCH_LOOP(S, NT, false)
+    if (af == 2) UTM_LAUNCH_LOOP(S, NT, 2); \
+    else if (af) UTM_LAUNCH_LOOP(S, NT, 1); \
+    else UTM_LAUNCH_LOOP(S, NT, 0)
     switch (sh.steps * 2 + (use_nt ? 1 : 0)) {
     case 17: UTM_LAUNCH_LOOP2(8, true); break;
     case 16: UTM_LAUNCH_LOOP2(8, false); break;
@@ -597,8 +635,12 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // AF runs start with short batches: the dense -> sparse kernel switch is taken at a batch boundary
         // ... and so is the switch to decremental iterations
         // (the AF form of the persistent loop needs no host decision inside a batch: 256 iterations per launch, as for integers)
-        const bool loop_af_batch = batch_env <= 0 && !c->decr_enabled && loop_af_ready(c, false) && loop_shape(c, true).ok;
-        const i64 this_batch = loop_af_batch                                                  ? 256
+        const int form_hint = (batch_env <= 0 && !c->decr_enabled && !c->loop_unresolved) ? loop_af_form(c, false) : 0;
+        const bool loop_af_batch = form_hint && loop_shape(c, form_hint).ok;
+        // (interval form with deferred exact scores: a launch logs one newly-covered mask per row, UTM_DEFER_SLOTS slots)
+        const i64 this_batch = c->loop_unresolved                                             ? 1
+                               : c->persist_backoff > 0                                       ? std::min<i64>(batch, c->persist_backoff)
+                               : loop_af_batch                                                ? ((form_hint == 2 && defer_active(c)) ? (i64)UTM_DEFER_SLOTS : 256)
                                : (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, c->iter < 8 ? 4 : 8)
                                : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, decr_first)
                                                                                             : batch;
@@ -621,14 +663,25 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // where the pick runs: inside the scoring launch on the only shard (1) and on a shard of the mailbox exchange (2)
         const int fuse_mode = mailbox_exchange(c) ? 2 : (c->n_ranks == 1 && c->n_local == c->n_total && !c->comm) ? 1 : 0;
         // short scans (and any matrix whose tile grid fits the resident blocks): the whole batch as ONE persistent launch
-        const bool loop_af = af_par && loop_af_ready(c, first_is_full);
-        const LoopShape loop = (!decr && fuse_mode == 1 && c->tune.fuse_pick && (c->af_mode == UTM_AF_NONE || loop_af)) ? loop_shape(c, loop_af) : LoopShape();
+        // An iteration that a persistent launch (interval form) scored but could not decide: the verification launch alone,
+        // as a batch of its own -- the accumulators and covered are current, nothing is pending.  (Byte accounting: the
+        // pass that scored it went uncounted when its launch ended; it is counted here.)
+        const bool verify_only = c->loop_unresolved && af_par && !first_is_full;
+        if (c->loop_unresolved) {
+            if (!verify_only) return fail(UTM_ESTATE, "an undecided iteration of the persistent loop cannot be finished in this mode (internal error)");
+            c->loop_unresolved = false;
+            HIP_TRY(hipMemsetAsync(&c->d_st->loop_unresolved, 0, sizeof(int), c->stream));
+        }
+        const int loop_af = (af_par && !verify_only) ? loop_af_form(c, first_is_full) : 0;
+        const LoopShape loop = (!decr && !verify_only && fuse_mode == 1 && c->tune.fuse_pick && (c->af_mode == UTM_AF_NONE || loop_af)) ? loop_shape(c, loop_af) : LoopShape();
         if (loop.ok) n = std::min<i64>(n, 256);  // (a launch's record carries an 8-bit iteration tag; UTM_BATCH may ask for more)
+        if (loop.ok && loop_af == 2 && defer_active(c)) n = std::min<i64>(n, UTM_DEFER_SLOTS);
         if (loop.ok) TRY(enqueue_loop(c, loop, (int)n, loop_af));
         for (i64 j = 0; j < n && !loop.ok; ++j) {
             bool picked = false;
             c->enq_iter = c->iter + j;  // (exact unless the loop ends first -- and then these launches do nothing)
-            if (decr) TRY(enqueue_score_decr(c));
+            if (verify_only) picked = false;
+            else if (decr) TRY(enqueue_score_decr(c));
             else TRY(enqueue_score(c, false, fuse_mode, &picked));
             if (!picked) TRY(enqueue_pick_and_exchange(c, decr));
             if (af_par && j == 0 && first_is_full) hipLaunchKernelGGL(k_count_sum, dim3(1), dim3(1024), 0, c->stream, c->d_st, c->d_act, c->d_cnt, 1);
@@ -648,6 +701,22 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
             continue;
         }
         if (loop.ok) c->persist_iterations += c->iter - before;
+        if (loop.ok && c->h_st->loop_unresolved) {
+            // the launch ended early, with an iteration scored but not decided: the next batch is its verification launch
+            c->loop_unresolved = true;
+            c->persist_unresolved += 1;
+            n = c->iter - before;
+            // ties the picker cannot settle come in runs (long twin columns): when launches keep ending after a few rows,
+            // the next 4, 8, ... 64 iterations run as launches before the loop is tried again
+            if (n < 4) {
+                c->persist_backoff_len = std::min<i64>(64, std::max<i64>(4, c->persist_backoff_len * 2));
+                c->persist_backoff = c->persist_backoff_len;
+            } else if (n >= 16) {
+                c->persist_backoff_len = 0;
+            }
+        } else if (!loop.ok && c->persist_backoff > 0 && !verify_only) {
+            c->persist_backoff -= std::max<i64>(1, c->iter - before);
+        }
         enq += n;
         if (rccl_needs_root(c) && c->iter > before && !c->finished) {
             // second half of the RCCL exchange: the winner's column from its owner into every shard's winner-column
@@ -816,6 +885,7 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->af_deferred_rows = c->deferred_rows;
     out->persist_launches = c->persist_launches;
     out->persist_iterations = c->persist_iterations;
+    out->persist_unresolved = c->persist_unresolved;
     out->rccl_ranks = 0;
     if (c->comm) {
         int n = 0;
@@ -889,7 +959,7 @@ extern "C" int utm_set_profile(utm_ctx *c, int32_t on)
 }
 
 #ifdef UTM_DEBUG_STAMPS
-extern "C" int utm_dbg_loop_stamps(utm_ctx *c, uint64_t *out /* 256 x 8 */, uint64_t *wave_t /* 2 x 8192 */)
+extern "C" int utm_dbg_loop_stamps(utm_ctx *c, uint64_t *out /* 256 x 16 */, uint64_t *wave_t /* 2 x 8192 */)
 {
     std::vector<LoopSync> h(1);
     HIP_TRY(copy_sync(c, h.data(), c->d_loop_sync, sizeof(LoopSync), hipMemcpyDeviceToHost));

@@ -195,7 +195,9 @@ extern "C" int utm_reset(utm_ctx *c)
     c->active_ub = (unsigned)act.size();
     c->finished = false;
     c->score_launches = 0;
-    c->persist_launches = c->persist_iterations = 0;
+    c->persist_launches = c->persist_iterations = c->persist_unresolved = 0;
+    c->loop_unresolved = false;
+    c->persist_backoff = c->persist_backoff_len = 0;
     c->score_ms = 0;
     c->algo_bytes = 0;
     c->ev_used = 0;

@@ -5,9 +5,9 @@
 #include "pick.hip.h"
 #include "score_int.hip.h"
 #include "score_af.hip.h"
-#include "loop_int.hip.h"
 #include "covered.hip.h"
 #include "decremental.hip.h"
 #include "af_verify.hip.h"
+#include "loop_int.hip.h"
 #include "af_defer.hip.h"
 #include "ingest.hip.h"

@@ -46,18 +46,29 @@
 #include "pick.hip.h"
 #include "score_int.hip.h"
 
+#define UTM_LOOP_MAX_CHAINERS 8
 struct LoopSync {
     u64 pub[2];              // W0, W1
     u64 pad0[14];
     unsigned arrive[8 * 32];  // census counters, one per XCD slot (blockIdx & 7), 128 B apart
     unsigned go;              // the picker's census verdict: 1 go, 2 abort
     unsigned worker_timeout;  // a worker gave up waiting for a record (diagnostic)
-    unsigned pad1[30];
+    // interval form: the picker's request to the chainer blocks -- sums on record for these samples, please (chainer j
+    // takes samples 2j and 2j + 1)
+    unsigned req_s[2 * UTM_LOOP_MAX_CHAINERS];
+    unsigned pad1[30 - 2 * UTM_LOOP_MAX_CHAINERS];
+    u64 req_hdr;              // id << 8 | number of samples; id = epoch << 8 | round within the iteration (written last)
+    u64 pad2[15];
+    u64 req_done[UTM_LOOP_MAX_CHAINERS];  // the id chainer j has served
+    u64 pad3[16 - UTM_LOOP_MAX_CHAINERS];
+    // ... and every record's first word, by iteration of the launch: the chainer follows the records at its own pace (a
+    // worker cannot miss one -- the picker waits for its counts -- the chainer can)
+    u64 rec_log[256];
 #ifdef UTM_DEBUG_STAMPS
     // per iteration of the launch (s_memrealtime, 10 ns ticks): 0 picker saw every count word complete, 1 record published,
     // 2 block 1 / wave 0 finished its positions, 3 ... saw the record, 4 ... tile updated, 5 unused, 6 block 1 / wave 0 first
     // batch of the next iteration counted
-    u64 stamps[256][8];
+    u64 stamps[256][16];  // [0..7] the hand-off's stages; [8..15] the interval form's picker (candidates, chain stages)
     u64 wave_t[2][8192];  // iteration UTM_STAMP_ITER of the launch: every wave's [0] tile-ready and [1] last-partial times
 #endif
 };
@@ -111,21 +122,319 @@ __device__ __forceinline__ LoopRec loop_read_record(const LoopSync *sync, unsign
 }
 
 // ------------------------------------------------------------------------------------------------ the picker
+struct LoopCand {  // interval form: a sample whose score interval reaches the best lower bound
+    double val;    // unweighted: the estimate, or the sequential float64 sum (on record / from a chain of this iteration)
+    u64 cnt;
+    unsigned s, pos;
+    int exact, pad;
+};
+#ifndef UTM_IV_EXPERIMENT
+#define UTM_IV_EXPERIMENT 0  // timing experiment only (wrong rows): 1 = no chains, ties go to the estimates
+#endif
+#ifndef UTM_LOOP_IV_BLOCKS
+#define UTM_LOOP_IV_BLOCKS 4  // interval form: waves per SIMD the kernel is compiled for (a block is two waves per SIMD: 3 would leave ONE block per CU)
+#endif
+#define UTM_LOOP_CHAIN_CAP 512  // addends of one chain inside the launch (one per thread of the chainer); more: the host's launches take the iteration
+#define UTM_LOOP_REQ_SPINS (1u << 18)     // x s_sleep(4): ~0.1 s before the picker gives up on the chainer (the iteration then goes to the host)
+#define UTM_LOOP_CHAINER_IDLE (1u << 22)  // idle polls (~0.5 us each) before the chainer takes the launch for lost
 struct LoopPickLds {
     IntCand wbest[UTM_LOOP_WAVES];
     double wval[UTM_LOOP_WAVES];  // (AF: the waves' best scores; count / sample / position travel in wbest)
     unsigned n_active;
     int stop, failed, pad;
     unsigned best_pos, moved;  // the decision's change to act[] (every thread keeps its own entries current)
+    // interval form
+    double wlo[UTM_LOOP_WAVES];  // the waves' best lower bounds
+    unsigned n_c;                // candidates appended this iteration (may exceed UTM_MAX_CAND: overflow)
+    int any_inexact, unresolved;
+    int req_ok;
+    LoopCand cand[UTM_MAX_CAND];
 };
 
 __device__ __forceinline__ void loop_publish(LoopSync *sync, unsigned epoch, int stop, int removed, unsigned winner, unsigned best_pos,
-                                             unsigned moved)
+                                             unsigned moved, bool log = false)
 {
     const u64 w1 = ((u64)(epoch & 0xFFu) << 56) | ((u64)(best_pos & 0xFFFFFFFu) << 28) | (u64)(moved & 0xFFFFFFFu);
     const u64 w0 = ((u64)(epoch & UTM_LOOP_EPOCH_MASK) << 40) | ((u64)(stop ? 1 : 0) << 39) | ((u64)(removed ? 1 : 0) << 38) | (u64)winner;
     __hip_atomic_store(&sync->pub[1], w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&sync->pub[0], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (log) __hip_atomic_store(&sync->rec_log[(epoch - 1) & 255u], w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct LoopAf {
+    const unsigned *afbits;  // this chunk's fixed-point table (af_fixed), or nullptr
+    u64 *afd0, *afd1;        // per position: this iteration's decrease of the fixed-point sum (by iteration parity)
+    // interval form (AFM == 2)
+    const void *af_raw;      // the AF values as the caller gave them: float or double per variant (PickArgs::af_is_f64)
+    u64 *priv;               // the picker's own copy of `covered`, kept current (the chunk's second covered buffer)
+    u64 *newly_log;          // deferred exact scores: the log of newly-covered masks (af_defer.hip.h), or nullptr
+    u64 log_stride;          // words between two slots of the log
+    int spec_min_ticks;      // the chainers work ahead while iterations take longer than this (10 ns ticks; < 0: never)
+    int n_chainers;          // 1..UTM_LOOP_MAX_CHAINERS blocks at the end of the grid; priv holds one covered mask for each
+};
+
+// What the picker of the interval form needs beyond the words: the matrix itself and an up-to-date `covered` (chains).
+struct LoopIv {
+    const u64 *cols;
+    u64 wp;
+    const u64 *covered;  // as the launch found it
+    Pending pend;
+    const void *af_raw;
+    u64 *priv;
+    void *scratch;       // LDS: 2 x UTM_LOOP_CHAIN_CAP doubles
+    int spec_min_ticks;
+    unsigned chainer, n_chainers;  // (a chainer: which one of how many; the picker: how many)
+};
+
+// ------------------------------------------------------------------------------------------------ the chainer
+// Interval form: the LAST block of the grid neither picks nor streams -- it keeps sequential float64 sums on record
+// (PickArgs::known_*: the sum and the count it belongs to; a sample's uncovered set only shrinks, so the sum holds while
+// the count does) for the samples that may have to be told apart soon, so that the picker finds them there when intervals
+// overlap.  It follows the picker's records and keeps a covered mask of its own (priv: the chunk's second covered buffer);
+// between two records it serves the picker's requests (samples whose sums are needed NOW) and otherwise works ahead: the
+// samples with the best estimates that have no valid sum on record.
+//
+// A chain (select.py:38-40: the float64 sum, in ascending variant order, over the variants a sample would newly cover), for
+// up to two samples at once, by the block's 512 threads: every set bit of column & ~priv is appended to its sample's list
+// in LDS (unordered, one LDS atomic each -- at most UTM_LOOP_CHAIN_CAP of them, a longer list leaves no record), an
+// entry's rank is the number of smaller entries, the values go to LDS in rank order and one wave per sample adds them one
+// by one (ordered_sum64).  Word w of priv is only ever touched by thread w % 512.
+struct LoopChainLds {
+    LoopRec rec;
+    u64 req, now;  // (thread 0's clock: every decision below is the same in all threads)
+    unsigned chain_n[2];
+    unsigned spec_s[2], spec_n;
+    int go, bad;
+    double wval[UTM_LOOP_WAVES];
+    unsigned ws[UTM_LOOP_WAVES];
+};
+
+__device__ __forceinline__ void loop_chain2(const PickArgs &a, const LoopIv &iv, LoopChainLds *L, unsigned s0, unsigned s1, bool two)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *vals0 = reinterpret_cast<double *>(iv.scratch), *vals1 = vals0 + UTM_LOOP_CHAIN_CAP;
+    unsigned *list0 = reinterpret_cast<unsigned *>(vals0), *list1 = reinterpret_cast<unsigned *>(vals1);
+    if (threadIdx.x < 2) L->chain_n[threadIdx.x] = 0;
+    __syncthreads();
+    // 16 bytes per lane and load, 18 loads in flight: a chr22-sized column (17k words) is three rounds of memory latency
+    const v2q *c0 = reinterpret_cast<const v2q *>(iv.cols + (u64)s0 * iv.wp), *c1 = reinterpret_cast<const v2q *>(iv.cols + (u64)s1 * iv.wp);
+    const v2q *pr = reinterpret_cast<const v2q *>(iv.priv);
+    const u64 pairs = iv.wp / 2;
+    constexpr int LQ = 6;
+    for (u64 base = 0; base < pairs; base += (u64)UTM_LOOP_THREADS * LQ) {
+        v2q pv[LQ], x0[LQ], x1[LQ];
+#pragma unroll
+        for (int q = 0; q < LQ; ++q) {
+            const u64 i = base + (u64)q * UTM_LOOP_THREADS + threadIdx.x;
+            const bool in = i < pairs;
+            const v2q ones = {~0ull, ~0ull}, zero = {0ull, 0ull};
+            pv[q] = in ? pr[i] : ones;
+            x0[q] = in ? c0[i] : zero;
+            x1[q] = (in && two) ? c1[i] : zero;
+        }
+#pragma unroll
+        for (int q = 0; q < LQ; ++q) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const u64 v0 = ((base + (u64)q * UTM_LOOP_THREADS + threadIdx.x) * 2 + d) * 64;
+                u64 y = x0[q][d] & ~pv[q][d];
+                while (y) {
+                    const unsigned slot = atomicAdd(&L->chain_n[0], 1u);
+                    if (slot < UTM_LOOP_CHAIN_CAP) list0[slot] = (unsigned)(v0 + (u64)__builtin_ctzll(y));
+                    y &= y - 1;
+                }
+                y = x1[q][d] & ~pv[q][d];
+                while (y) {
+                    const unsigned slot = atomicAdd(&L->chain_n[1], 1u);
+                    if (slot < UTM_LOOP_CHAIN_CAP) list1[slot] = (unsigned)(v0 + (u64)__builtin_ctzll(y));
+                    y &= y - 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    unsigned n0 = L->chain_n[0], n1 = two ? L->chain_n[1] : 0u;
+    const bool ok0 = n0 <= UTM_LOOP_CHAIN_CAP, ok1 = two && n1 <= UTM_LOOP_CHAIN_CAP;
+    if (!ok0) n0 = 0;
+    if (!ok1) n1 = 0;
+    unsigned r0 = 0, r1 = 0;
+    double v0 = 0.0, v1 = 0.0;
+    const u64 e_cap = iv.wp * 64;
+    if (threadIdx.x < n0) {
+        unsigned e = list0[threadIdx.x];
+        if ((u64)e >= e_cap) { L->bad = 1; e = 0; }  // (cannot happen; no record then, and the picker hands the iteration to the host)
+        v0 = a.af_is_f64 ? static_cast<const double *>(iv.af_raw)[e] : (double)static_cast<const float *>(iv.af_raw)[e];
+        for (unsigned j = 0; j < n0; ++j) r0 += list0[j] < e ? 1u : 0u;
+    }
+    if (threadIdx.x < n1) {
+        unsigned e = list1[threadIdx.x];
+        if ((u64)e >= e_cap) { L->bad = 2; e = 0; }
+        v1 = a.af_is_f64 ? static_cast<const double *>(iv.af_raw)[e] : (double)static_cast<const float *>(iv.af_raw)[e];
+        for (unsigned j = 0; j < n1; ++j) r1 += list1[j] < e ? 1u : 0u;
+    }
+    __syncthreads();  // every rank is known: the lists make room for the values
+    if (threadIdx.x < n0) vals0[r0] = v0;
+    if (threadIdx.x < n1) vals1[r1] = v1;
+    __syncthreads();
+    if (((wave == 0 && ok0) || (wave == 1 && ok1)) && !L->bad) {
+        const unsigned n = wave ? n1 : n0, sc = wave ? s1 : s0;
+        const double *vals = wave ? vals1 : vals0;
+        double acc = 0.0;
+        for (unsigned t = 0; t < n; t += 64) acc = ordered_sum64(acc, t + lane < n ? vals[t + lane] : 0.0);
+        if (lane == 0) {
+            // the sum first, then the count that validates it (the picker reads them the other way round)
+            __hip_atomic_store(reinterpret_cast<u64 *>(&a.known_val[sc]), __builtin_bit_cast(u64, acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&a.known_cnt[sc], (u64)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void loop_chainer(const PickArgs &a, LoopSync *sync, const LoopIv &iv, LoopChainLds *L, unsigned n_act)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // covered as the launch found it, with the pending winner folded in (as the workers' tiles)
+    {
+        const u64 *wcol = iv.pend.fuse ? pending_column(a.st, iv.cols, iv.wp, iv.pend) : nullptr;
+        for (u64 i = threadIdx.x; i < iv.wp / 2; i += UTM_LOOP_THREADS) {  // (a 16-byte pair of words is only ever touched by thread pair % 512)
+            iv.priv[2 * i] = iv.covered[2 * i] | (wcol ? wcol[2 * i] : 0ull);
+            iv.priv[2 * i + 1] = iv.covered[2 * i + 1] | (wcol ? wcol[2 * i + 1] : 0ull);
+        }
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&sync->arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned g = 0;
+        for (unsigned spin = 0; spin < UTM_LOOP_WAIT_SPINS; ++spin) {
+            g = __hip_atomic_load(&sync->go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        L->go = g == 1;
+    }
+    if (threadIdx.x == 0) L->bad = 0;
+    __syncthreads();
+    if (!L->go) return;
+    unsigned applied = 0;  // records followed so far: priv is covered as iteration `applied` of the launch sees it
+    u64 served = 0, t_last = 0;
+    unsigned idle = 0, spec_budget = 0;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const u64 w0 = __hip_atomic_load(&sync->rec_log[applied & 255u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LoopRec lr;
+            lr.ok = (w0 >> 40) == (u64)((applied + 1) & UTM_LOOP_EPOCH_MASK);
+            lr.stop = (int)(w0 >> 39 & 1);
+            lr.removed = (int)(w0 >> 38 & 1);
+            lr.winner = (unsigned)(w0 & 0xFFFFFFFFull);
+            lr.best_pos = lr.moved = 0;
+            L->rec = lr;
+            L->req = __hip_atomic_load(&sync->req_hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            L->now = (u64)wall_clock64();
+        }
+        __syncthreads();
+        const LoopRec r = L->rec;
+        const u64 req = L->req, now = L->now;
+        __syncthreads();
+        if (r.ok) {
+            if (r.stop) return;
+            const v2q *wc = reinterpret_cast<const v2q *>(iv.cols + (u64)r.winner * iv.wp);
+            v2q *pr = reinterpret_cast<v2q *>(iv.priv);
+            const u64 pairs = iv.wp / 2;
+            constexpr int LQ = 8;
+            for (u64 base = 0; base < pairs; base += (u64)UTM_LOOP_THREADS * LQ) {
+                v2q add[LQ], old[LQ];
+#pragma unroll
+                for (int q = 0; q < LQ; ++q) {
+                    const u64 i = base + (u64)q * UTM_LOOP_THREADS + threadIdx.x;
+                    const v2q zero = {0ull, 0ull};
+                    add[q] = i < pairs ? wc[i] : zero;
+                    old[q] = i < pairs ? pr[i] : zero;
+                }
+#pragma unroll
+                for (int q = 0; q < LQ; ++q)
+                    if ((add[q][0] & ~old[q][0]) | (add[q][1] & ~old[q][1])) pr[base + (u64)q * UTM_LOOP_THREADS + threadIdx.x] = old[q] | add[q];
+            }
+            // one chain ahead per record, started now -- and only while iterations are long enough for it to be over before
+            // the picker may ask for something (a request waits for the chain in progress)
+            spec_budget = (iv.spec_min_ticks >= 0 && t_last && now - t_last > (u64)iv.spec_min_ticks) ? 1u : 0u;
+            t_last = now;
+            applied += 1;
+            n_act -= r.removed ? 1u : 0u;
+            idle = 0;
+            continue;
+        }
+        const u64 id = req >> 8;
+        if (id != served && (id >> 8) == (u64)applied + 1) {
+            // the picker is waiting: these samples' sums, two at a time
+            const unsigned n = (unsigned)(req & 0xFFu), i = 2 * iv.chainer;
+            if (i < n) {
+                const unsigned s0 = __hip_atomic_load(&sync->req_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool two = i + 1 < n;
+                const unsigned s1 = two ? __hip_atomic_load(&sync->req_s[i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s0;
+                loop_chain2(a, iv, L, s0, s1, two);
+                if (threadIdx.x == 0) __hip_atomic_store(&sync->req_done[iv.chainer], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            served = id;
+            idle = 0;
+            continue;
+        }
+        // nothing asked for: work ahead -- the two best estimates (by wave) without a valid sum on record
+        if (!spec_budget) {
+            if (++idle > UTM_LOOP_CHAINER_IDLE) return;  // (no record for seconds: the launch is lost, its picker reports it)
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        spec_budget = 0;
+        double bv = -__builtin_inf();
+        unsigned bs = 0xFFFFFFFFu;
+        for (unsigned i = threadIdx.x; i < n_act; i += UTM_LOOP_THREADS) {
+            const unsigned s = __hip_atomic_load(&a.act[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (s >= a.n_local || s % iv.n_chainers != iv.chainer) continue;  // (every chainer works ahead on its own residue class)
+            const u64 c = __hip_atomic_load(&a.cnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const u64 kc = __hip_atomic_load(&a.known_cnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == 0 || c == kc || c > (u64)UTM_LOOP_CHAIN_CAP) continue;
+            double v = (double)(i64)__hip_atomic_load(reinterpret_cast<u64 *>(&a.afsum[s]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * a.af_scale;
+            if (a.weights) v *= a.weights[a.first + s];
+            if (v > bv) {
+                bv = v;
+                bs = s;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o, 64);
+            const unsigned os = __shfl_xor(bs, o, 64);
+            if (ov > bv || (ov == bv && os < bs)) {
+                bv = ov;
+                bs = os;
+            }
+        }
+        if (lane == 0) {
+            L->wval[wave] = bv;
+            L->ws[wave] = bs;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned n = 0;
+            int w1 = -1;
+            for (int pass = 0; pass < 2; ++pass) {
+                int bw = -1;
+                for (int w8 = 0; w8 < UTM_LOOP_WAVES; ++w8)
+                    if (w8 != w1 && L->ws[w8] != 0xFFFFFFFFu && (bw < 0 || L->wval[w8] > L->wval[bw])) bw = w8;
+                if (bw < 0) break;
+                L->spec_s[n++] = L->ws[bw];
+                w1 = bw;
+            }
+            L->spec_n = n;
+        }
+        __syncthreads();
+        const unsigned n_spec = L->spec_n;
+        if (n_spec) {
+            loop_chain2(a, iv, L, L->spec_s[0], n_spec > 1 ? L->spec_s[1] : L->spec_s[0], n_spec > 1);
+            idle = 0;
+        }
+    }
 }
 
 // AF = false: scores are the counts themselves (unweighted integer loop).  AF = true: the exact fixed-point AF phase
@@ -143,13 +452,20 @@ __device__ __forceinline__ bool better_af(const AfCand &a, const AfCand &b)
     return a.val > b.val || (a.val == b.val && a.s < b.s);
 }
 // MODE 0: unweighted integer scores.  1: the AF form.  2: integer counts times per-sample weights (full counts in the
-// words as in MODE 0, float64 products compared as in MODE 1).
+// words as in MODE 0, float64 products compared as in MODE 1).  3: the interval form of the AF loop -- words and
+// accumulators as in MODE 1, but the fixed-point sums only ESTIMATE the reference's float64 sums (float64 AF values, or
+// float32 ones whose sums leave the exact range): a sample's score is an interval (af_interval_regs, as k_cand's), the
+// samples whose intervals reach the best lower bound are the candidates; one candidate is the winner, several are told
+// apart by their sequential float64 sums -- on record from an earlier chain, or chained here (loop_chain2).  What the
+// picker cannot settle (more than UTM_MAX_CAND candidates, a chain longer than UTM_LOOP_CHAIN_CAP) ends the launch with
+// the iteration scored but undecided (IterState::loop_unresolved): the host's verification launch decides it.
 template <int MODE>
 __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u64 *cnt0, u64 *cnt1, u64 *afd0, u64 *afd1, unsigned *claim,
-                                            unsigned n_tiles, unsigned n_blocks, int k_batch, LoopPickLds *L)
+                                            unsigned n_tiles, unsigned n_blocks, int k_batch, LoopPickLds *L, const LoopIv &iv)
 {
-    constexpr bool AF = MODE == 1;   // decrease words, per-sample accumulators
-    constexpr bool DBL = MODE != 0;  // float64 scores: (score descending, sample ascending), the negative-best rule
+    constexpr bool IV = MODE == 3;
+    constexpr bool AF = MODE == 1 || IV;  // decrease words, per-sample accumulators
+    constexpr bool DBL = MODE != 0;       // float64 scores: (score descending, sample ascending), the negative-best rule
     IterState *st = a.st;
     const int lane = threadIdx.x & 63;
     // census: every block of the grid (this one included) has counted in => every block is resident
@@ -169,7 +485,6 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
     }
     __syncthreads();
     if (L->stop) return;
-
     unsigned n_active = st->n_active;  // (written before the launch)
     i64 iter = 0, tot = 0, n_active_total = 0;
     unsigned last_act = 0;
@@ -185,6 +500,7 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
     const bool one_chunk = n_active <= UTM_LOOP_THREADS * UTM_LOOP_E;
     unsigned s[UTM_LOOP_E];
     u64 c_keep[UTM_LOOP_E], a_keep[UTM_LOOP_E];  // (AF: the accumulators of this thread's samples)
+    i64 chain_events = 0;
 #pragma unroll
     for (int e = 0; e < UTM_LOOP_E; ++e) {
         s[e] = 0;
@@ -202,7 +518,8 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
         }
         IntCand best{0, 0xFFFFFFFFu, 0};
         AfCand fbest{-__builtin_inf(), 0, 0xFFFFFFFFu, 0};
-        int failed = 0;
+        double best_lo = -__builtin_inf();
+        int failed = 0, any_inexact = 0;
         u64 *afd = (k & 1) ? afd1 : afd0;
         // UTM_LOOP_E words per thread in flight, EVERY incomplete word of the chunk re-read every round: once the last
         // partial has landed, the next round sees the chunk complete (2,504 samples are one chunk)
@@ -257,11 +574,20 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                             __hip_atomic_store(&a.cnt[s[e]], c_keep[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             __hip_atomic_store(reinterpret_cast<u64 *>(&a.afsum[s[e]]), a_keep[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        const u64 count = AF ? c_keep[e] : d_cnt;  // (MODE 2: the word IS the count)
-                        double val = AF ? (double)(i64)a_keep[e] * a.af_scale : (double)count;  // exact: < 2^53 units, power-of-two scale
-                        if (a.weights) val *= a.weights[a.first + s[e]];
-                        const AfCand cand{val, count, s[e], i0 + e * UTM_LOOP_THREADS};
-                        if (better_af(cand, fbest)) fbest = cand;
+                        if (IV) {
+                            double lo, hi, est;
+                            bool exact, est_exact;
+                            af_interval_regs(a, s[e], c_keep[e], (i64)a_keep[e], ~0ull, 0.0, lo, hi, est, exact, est_exact);
+                            best_lo = lo > best_lo ? lo : best_lo;
+                            any_inexact |= est_exact ? 0 : 1;
+                            __builtin_amdgcn_sched_barrier(0);  // (one sample's interval at a time: five interleaved ones do not fit the registers)
+                        } else {
+                            const u64 count = AF ? c_keep[e] : d_cnt;  // (MODE 2: the word IS the count)
+                            double val = AF ? (double)(i64)a_keep[e] * a.af_scale : (double)count;  // exact: < 2^53 units, power-of-two scale
+                            if (a.weights) val *= a.weights[a.first + s[e]];
+                            const AfCand cand{val, count, s[e], i0 + e * UTM_LOOP_THREADS};
+                            if (better_af(cand, fbest)) fbest = cand;
+                        }
                     }
                     need &= ~((fin ? 1u : 0u) << e);
                 }
@@ -273,7 +599,10 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            if (!DBL) {
+            if (IV) {
+                const double other = __shfl_xor(best_lo, o, 64);
+                best_lo = other > best_lo ? other : best_lo;
+            } else if (!DBL) {
                 IntCand other;
                 other.cnt = __shfl_xor(best.cnt, o, 64);
                 other.s = __shfl_xor(best.s, o, 64);
@@ -291,14 +620,113 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
         t_work = (u64)wall_clock64() - t_pub;  // (this thread's words; all threads finish within a round of each other)
         if (threadIdx.x == 0) L->failed = 0;
         if (threadIdx.x == 0) UTM_LSTAMP(sync, k, 0);
+        unsigned n_c = 0;
+        if (IV) {
+            if (lane == 0) L->wlo[threadIdx.x >> 6] = best_lo;
+            if (threadIdx.x == 0) {
+                L->n_c = 0;
+                L->any_inexact = 0;
+            }
+        }
         __syncthreads();
-        if (DBL) best = IntCand{fbest.cnt, fbest.s, fbest.pos};
-        if (lane == 0) {
-            L->wbest[threadIdx.x >> 6] = best;
-            if (DBL) L->wval[threadIdx.x >> 6] = fbest.val;
+        if (IV) {
+            // the candidates: every sample whose interval reaches the best lower bound (this thread's samples are in its
+            // registers: the intervals are made again rather than kept).  Sums on record are NOT used here -- an estimate's
+            // interval contains the sum, so the candidates are a superset of k_cand's -- only looked up for the candidates.
+            best_lo = L->wlo[0];
+#pragma unroll
+            for (int w8 = 1; w8 < UTM_LOOP_WAVES; ++w8) best_lo = L->wlo[w8] > best_lo ? L->wlo[w8] : best_lo;
+#pragma unroll
+            for (int e = 0; e < UTM_LOOP_E; ++e) {
+                const unsigned i = threadIdx.x + e * UTM_LOOP_THREADS;
+                if (i >= n_active || failed) continue;
+                double lo, hi, est;
+                bool exact, est_exact;
+                af_interval_regs(a, s[e], c_keep[e], (i64)a_keep[e], ~0ull, 0.0, lo, hi, est, exact, est_exact);
+                if (hi >= best_lo) {
+                    const unsigned slot = atomicAdd(&L->n_c, 1u);
+                    if (slot < UTM_MAX_CAND) L->cand[slot] = LoopCand{est, c_keep[e], s[e], i, exact ? 1 : 0, 0};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (any_inexact) L->any_inexact = 1;
+        } else {
+            if (DBL) best = IntCand{fbest.cnt, fbest.s, fbest.pos};
+            if (lane == 0) {
+                L->wbest[threadIdx.x >> 6] = best;
+                if (DBL) L->wval[threadIdx.x >> 6] = fbest.val;
+            }
         }
         if (failed) L->failed = 1;
         __syncthreads();
+        if (IV) {
+            // sequential float64 sums where the intervals do not settle the iteration (k_cand's rule): on record -- the
+            // chainer block works ahead -- or asked for now
+            n_c = L->n_c;
+            if (threadIdx.x == 0) UTM_LSTAMP(sync, k, 8);  // the candidates are listed
+            bool unresolved = n_c > UTM_MAX_CAND, asked = false;
+            if (!unresolved && n_c > 0 && !L->failed) {
+                bool inexact = (unsigned)lane < n_c && !L->cand[lane].exact;  // lane i of every wave: candidate i
+                const bool zero_est = inexact && L->cand[lane].val == 0.0;  // (every addend floored away, yet the score is > 0: select.py:51 compares it with 0)
+                const bool too_long = inexact && L->cand[lane].cnt > (u64)UTM_LOOP_CHAIN_CAP;
+                const bool chain_needed = UTM_IV_EXPERIMENT == 0 && __ballot(inexact) != 0 && (__ballot(zero_est) != 0 || !(a.af_skip_single && n_c == 1));
+                if (chain_needed && __ballot(too_long) != 0) {
+                    unresolved = true;
+                } else if (chain_needed) {
+                    u64 todo_before = 0;
+                    for (unsigned round = 0;; ++round) {
+                        // what is on record by now (the sum belongs to the count stored AFTER it)
+                        if (threadIdx.x < 64 && inexact) {
+                            const unsigned cs = L->cand[lane].s;
+                            if (__hip_atomic_load(&a.known_cnt[cs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L->cand[lane].cnt) {
+                                L->cand[lane].val = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<u64 *>(&a.known_val[cs]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                L->cand[lane].exact = 1;
+                            }
+                        }
+                        __syncthreads();
+                        if (threadIdx.x == 0 && round == 0) UTM_LSTAMP(sync, k, 9);  // the records have been looked up
+                        inexact = (unsigned)lane < n_c && !L->cand[lane].exact;
+                        u64 todo = __ballot(inexact);
+                        if (threadIdx.x == 0 && !todo) UTM_LSTAMP(sync, k, 11);  // every candidate's sum is known
+                        if (threadIdx.x == 0 && todo) UTM_LSTAMP(sync, k, 10);  // (the last request goes out)
+                        if (!todo) break;
+                        if (todo == todo_before) {  // (a served request that put nothing on record -- a chain longer than the chainers hold: the host decides)
+                            unresolved = true;
+                            break;
+                        }
+                        todo_before = todo;
+                        asked = true;
+                        // the first two per chainer still missing: to the chainers
+                        const u64 id = ((u64)((unsigned)k + 1) << 8) | (u64)(round & 0xFFu);
+                        if (threadIdx.x == 0) {
+                            unsigned n = 0;
+                            for (u64 t = todo; t && n < 2 * iv.n_chainers; t &= t - 1, ++n)
+                                __hip_atomic_store(&sync->req_s[n], L->cand[__builtin_ctzll(t)].s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __hip_atomic_store(&sync->req_hdr, (id << 8) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bool ok = true;
+                            for (unsigned j = 0; 2 * j < n && ok; ++j) {
+                                ok = false;
+                                for (unsigned spin = 0; spin < UTM_LOOP_REQ_SPINS; ++spin) {
+                                    if (__hip_atomic_load(&sync->req_done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == id) { ok = true; break; }
+                                    __builtin_amdgcn_s_sleep(4);
+                                }
+                            }
+                            L->req_ok = ok ? 1 : 0;
+                        }
+                        __syncthreads();
+                        if (!L->req_ok) {  // (the chainer is gone, or a chain came out longer than it holds: the host decides)
+                            unresolved = true;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (threadIdx.x == 0) {
+                L->unresolved = unresolved ? 1 : 0;
+            }
+            chain_events += asked ? 1 : 0;  // (IterState::chain_events: iterations whose pick had to wait for chains)
+        }
         if (threadIdx.x == 0) {
             const unsigned epoch = (unsigned)k + 1;
             int stop = 0;
@@ -307,10 +735,30 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                 st->xerror = 2;  // a partial count never arrived (a logic error, not a data condition)
                 st->done = 1;
                 stop = 1;
-                loop_publish(sync, epoch, 1, 0, 0, 0, 0);
+                loop_publish(sync, epoch, 1, 0, 0, 0, 0, IV);
+            } else if (IV && L->unresolved) {
+                // scored, not decided: the accumulators and (once the workers have left) covered are current, nothing is
+                // pending -- the host's verification launch makes this iteration's pick
+                st->prev_valid = 0;
+                st->loop_unresolved = 1;
+                stop = 1;
+                loop_publish(sync, epoch, 1, 0, 0, 0, 0, IV);
             } else {
                 double best_val = DBL ? fbest.val : 0.0;
-                for (int w8 = 1; w8 < UTM_LOOP_WAVES; ++w8) {
+                if (IV) {
+                    // every candidate's value is final (or it is the only one): mask / weight / argmax as pick_among_candidates
+                    AfCand m{-__builtin_inf(), 0, 0xFFFFFFFFu, 0};
+                    for (unsigned i = 0; i < n_c; ++i) {
+                        const LoopCand cd = L->cand[i];
+                        double v = cd.val;
+                        if (a.weights) v *= a.weights[a.first + cd.s];
+                        const AfCand o{v, cd.cnt, cd.s, cd.pos};
+                        if (better_af(o, m)) m = o;
+                    }
+                    best = IntCand{m.cnt, m.s, m.pos};
+                    best_val = m.val;
+                }
+                for (int w8 = 1; w8 < UTM_LOOP_WAVES && !IV; ++w8) {
                     if (!DBL) {
                         if (better_int(L->wbest[w8], best)) best = L->wbest[w8];
                     } else {
@@ -330,14 +778,14 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                     st->done = 1;  // (None, None): no row (select.py:51-52, :93-96)
                     a.res_idx[iter] = -1;
                     stop = 1;
-                    loop_publish(sync, epoch, 1, 0, 0, 0, 0);
+                    loop_publish(sync, epoch, 1, 0, 0, 0, 0, IV);
                 } else {
                     const unsigned moved = last_act;
                     last_act_used = moved;
                     const int finished = tot + (i64)best.cnt >= a.n_var_total;  // "Ran out of new variants" (select.py:110-112)
                     stop = finished || k + 1 >= k_batch;
                     // the record first: everything below is bookkeeping nobody inside the launch waits for
-                    loop_publish(sync, epoch, stop, 1, best.s, best.pos, moved);
+                    loop_publish(sync, epoch, stop, 1, best.s, best.pos, moved, IV);
                     __hip_atomic_store(&a.act[best.pos], moved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     a.res_idx[iter] = (i64)a.first + best.s;
                     a.res_new[iter] = (i64)best.cnt;
@@ -370,6 +818,10 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                 st->tot = tot;
                 st->n_active_total = n_active_total;
                 st->n_active = n_active;
+                if (IV) {
+                    st->chain_events += (u64)chain_events;
+                    st->all_exact = L->any_inexact ? 0 : 1;
+                }
             }
             L->n_active = n_active;
             L->stop = stop;
@@ -422,18 +874,16 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
 // newly = live & winner (made for free while the tile is updated), counts column & newly instead of column & live, and
 // gathers the fixed-point AF entries of the few surviving bits from the table in global memory (afbits; L2 / Infinity
 // Cache resident).  Same bytes streamed as the integer loop, same hand-off.
-struct LoopAf {
-    const unsigned *afbits;  // this chunk's fixed-point table (af_fixed), or nullptr
-    u64 *afd0, *afd1;        // per position: this iteration's decrease of the fixed-point sum (by iteration parity)
-};
-template <int STEPS, bool NT, bool AF>
-__global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp, const Pending pend,
+// AFM: 0 integer scores | 1 the AF form, exact fixed-point phase | 2 the AF form with score intervals (loop_picker<3>)
+template <int STEPS, bool NT, int AFM>
+__global__ __launch_bounds__(UTM_LOOP_THREADS, AFM == 2 ? UTM_LOOP_IV_BLOCKS : 4) void k_loop_int(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp, const Pending pend,
                                                   IterState *__restrict__ st, unsigned *__restrict__ act, u64 *__restrict__ cnt0,
                                                   u64 *__restrict__ cnt1, unsigned q_slots, unsigned *__restrict__ claim, int k_batch,
                                                   LoopSync *__restrict__ sync, const PickArgs pa, int drop_iter, int use_claims, int ahead_ticks, int ahead0_ticks,
                                                   const LoopAf laf)
 {
     static_assert(STEPS % 8 == 0 && STEPS <= 64, "a tile is 1..8 batches of 8 KiB");
+    constexpr bool AF = AFM != 0;
     __shared__ v4u live[STEPS * 64];  // ~covered of this worker's tile (STEPS KiB), for the whole launch
     __shared__ v4u newly_lds[AF ? STEPS * 64 : 1];  // AF: what the pending winner newly covers of the tile
     __shared__ LoopRec rec_lds;
@@ -447,12 +897,25 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
     constexpr unsigned TILE_WORDS = STEPS * UTM_STEP_WORDS;
     const unsigned n_tiles = (unsigned)((wp + TILE_WORDS - 1) / TILE_WORDS);
     if (blockIdx.x == 0) {
+        static_assert(sizeof(LoopPickLds) <= 8 * 64 * sizeof(v4u), "the picker's scratch lives in the tile of the smallest instantiation");
         LoopPickLds *lds = reinterpret_cast<LoopPickLds *>(&live[0]);
-        if (AF) loop_picker<1>(pa, sync, cnt0, cnt1, laf.afd0, laf.afd1, claim, n_tiles, gridDim.x, k_batch, lds);
-        else if (pa.weights) loop_picker<2>(pa, sync, cnt0, cnt1, nullptr, nullptr, claim, n_tiles, gridDim.x, k_batch, lds);
-        else loop_picker<0>(pa, sync, cnt0, cnt1, nullptr, nullptr, claim, n_tiles, gridDim.x, k_batch, lds);
+        const LoopIv iv{cols, wp, covered, pend, laf.af_raw, laf.priv, nullptr, 0, 0, (unsigned)laf.n_chainers};
+        if (AFM == 2) loop_picker<3>(pa, sync, cnt0, cnt1, laf.afd0, laf.afd1, claim, n_tiles, gridDim.x, k_batch, lds, iv);
+        else if (AFM == 1) loop_picker<1>(pa, sync, cnt0, cnt1, laf.afd0, laf.afd1, claim, n_tiles, gridDim.x, k_batch, lds, iv);
+        else if (pa.weights) loop_picker<2>(pa, sync, cnt0, cnt1, nullptr, nullptr, claim, n_tiles, gridDim.x, k_batch, lds, iv);
+        else loop_picker<0>(pa, sync, cnt0, cnt1, nullptr, nullptr, claim, n_tiles, gridDim.x, k_batch, lds, iv);
         return;
     }
+    if (AFM == 2 && blockIdx.x >= gridDim.x - (unsigned)laf.n_chainers) {  // (grid = picker + workers + chainers)
+        static_assert(sizeof(LoopChainLds) <= 8 * 64 * sizeof(v4u) && 2 * UTM_LOOP_CHAIN_CAP * sizeof(double) <= 8 * 64 * sizeof(v4u),
+                      "the chainer's scratch lives in the two tiles of the smallest instantiation");
+        const unsigned cj = blockIdx.x - (gridDim.x - (unsigned)laf.n_chainers);
+        const LoopIv iv{cols, wp, covered, pend, laf.af_raw, laf.priv + (u64)cj * wp, &newly_lds[0], laf.spec_min_ticks, cj, (unsigned)laf.n_chainers};
+        loop_chainer(pa, sync, iv, reinterpret_cast<LoopChainLds *>(&live[0]), head.n_active);
+        return;
+    }
+    // (interval form with deferred exact scores: the row a launch's first iteration logs, see below)
+    const i64 iter0 = (AFM == 2 && laf.newly_log) ? st->iter : 0;
     if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync->arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned w = blockIdx.x - 1;
     const unsigned tile = w % n_tiles, slot = w / n_tiles;
@@ -540,6 +1003,12 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
         for (int k = nsteps * 64 + threadIdx.x; k < STEPS * 64; k += UTM_LOOP_THREADS) {  // (a short tile's missing steps)
             live[k] = zero4;
             if (AF) newly_lds[k] = zero4;
+        }
+        // Deferred exact scores (af_defer.hip.h): what a row's winner newly covered is what its float64 score runs over --
+        // the mask goes into the row's slot of the log, as from a delta pass of k_score_afs (row = the pending winner's)
+        if (AFM == 2 && laf.newly_log && slot == 0 && wcol && iter0 >= 1) {
+            v4u *lg = reinterpret_cast<v4u *>(laf.newly_log + (u64)((iter0 - 1) % UTM_DEFER_SLOTS) * laf.log_stride + w0);
+            for (int k = threadIdx.x; k < nsteps * 64; k += UTM_LOOP_THREADS) lg[k] = wc[k] & ~cv[k];
         }
     }
     // the census verdict
@@ -768,9 +1237,12 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, 4) void k_loop_int(const u64 *__r
         // covered |= winner, in LDS: live &= ~winner's tile
         {
             const v4u *wc = reinterpret_cast<const v4u *>(cols + (u64)r.winner * wp + w0);
+            v4u *lg = (AFM == 2 && laf.newly_log && slot == 0)
+                          ? reinterpret_cast<v4u *>(laf.newly_log + (u64)((iter0 + k) % UTM_DEFER_SLOTS) * laf.log_stride + w0) : nullptr;
             for (int kk = threadIdx.x; kk < nsteps * 64; kk += UTM_LOOP_THREADS) {
                 const v4u w = wc[kk], l = live[kk];
                 if (AF) newly_lds[kk] = l & w;
+                if (AFM == 2 && lg) lg[kk] = l & w;  // (the winner of this launch's iteration k made row iter0 + k)
                 live[kk] = l & ~w;
             }
         }

@@ -126,7 +126,7 @@ struct Tune {
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
-    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, persist_tall_max_samples, persist_af, test_drop_arrival;
+    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, persist_tall_max_samples, persist_af, persist_af_interval, persist_spec_ticks, persist_chainers, test_drop_arrival;
     int mbox_spins_log2, test_mute_exchange;                                 // mailbox exchange: patience, test hook   // persistent loop kernel
 };
 struct KnobDef {
@@ -167,6 +167,9 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_PERSIST_TALL_MAX_SAMPLES", persist_tall_max_samples, 640),  // tiles of several batches (columns taller than 32 x 8 KiB) only up to this many samples
     UTM_KNOB_I("UTM_PERSIST_MAX_SAMPLES", persist_max_samples, 2560),  // (one chunk of count words for the picker: UTM_LOOP_THREADS x UTM_LOOP_E)
     UTM_KNOB_I("UTM_PERSIST_AF", persist_af, 1),  // the AF form (exact float32 phase) of the persistent loop
+    UTM_KNOB_I("UTM_PERSIST_SPEC_TICKS", persist_spec_ticks, 1000),  // interval form: the chainer works ahead (one chain per record) while iterations take longer than this many 10 ns ticks -- a request waits for a chain in progress; -1: never
+    UTM_KNOB_I("UTM_PERSIST_CHAINERS", persist_chainers, 4),  // interval form: blocks that keep sequential float64 sums on record (1..8; a request for 2 x this many samples is served in one go)
+    UTM_KNOB_I("UTM_PERSIST_AF_INTERVAL", persist_af_interval, 1),  // ... and its interval form (float64 AF values; float32 sums outside the exact range): candidates and chains inside the picker
     UTM_KNOB_I("UTM_PERSIST_CLAIMS", persist_claims, 1),
     UTM_KNOB_I("UTM_PERSIST_AHEAD0_TICKS", persist_ahead0_ticks, 0),
     UTM_KNOB_I("UTM_PERSIST_AHEAD_TICKS", persist_ahead_ticks, 400),  // 10 ns ticks: the second run-ahead batch goes out this long before the record is due (0: at once)
@@ -244,10 +247,15 @@ struct utm_ctx {
     u64 *d_cnt_alt = nullptr;          // persistent loop: the count words of odd iterations (loop_int.hip.h)
     LoopSync *d_loop_sync = nullptr;   // ... its census counters and the picker's record
     u64 *d_loop_w[4] = {nullptr, nullptr, nullptr, nullptr};  // ... AF form: per-position count-decrease (2) and sum-decrease (2) words
+    u64 *d_loop_priv = nullptr;        // ... interval form: the chainers' covered masks (one column each)
+    size_t loop_priv_words = 0;
     unsigned *d_claim = nullptr;       // ... its position claim counters (sized for the tile grid at the first launch)
     size_t claim_bytes = 0;
     bool persist_off = false;          // ... a census failed on this context (not every block resident): launch per iteration from now on
     i64 persist_launches = 0, persist_iterations = 0;  // statistics since the last utm_reset
+    i64 persist_unresolved = 0;        // ... launches of the interval form that left their last iteration to the verification launch
+    bool loop_unresolved = false;      // ... and that iteration is still to be decided (utm_run)
+    i64 persist_backoff = 0, persist_backoff_len = 0;  // ... iterations to run as launches before the interval form is tried again
     i64 *d_afsum = nullptr;            // n_local
     double *d_fscore = nullptr;        // n_local
     unsigned *d_act = nullptr;         // n_local
@@ -473,7 +481,7 @@ extern "C" int utm_ctx_destroy(utm_ctx *c)
     (void)hipFree(c->d_segs); (void)hipFree(c->chain_fast.counts); (void)hipFree(c->chain_fast.vals);
     (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);
     (void)hipFree(c->d_cnt_keep); (void)hipFree(c->d_afsum_keep); (void)hipFree(c->d_listn);
-    (void)hipFree(c->d_cnt_alt); (void)hipFree(c->d_loop_sync); (void)hipFree(c->d_claim);
+    (void)hipFree(c->d_cnt_alt); (void)hipFree(c->d_loop_sync); (void)hipFree(c->d_claim); (void)hipFree(c->d_loop_priv);
     for (auto *w : c->d_loop_w) (void)hipFree(w);
     (void)hipFree(c->d_state); (void)hipFree(c->d_weights); (void)hipFree(c->d_cnt); (void)hipFree(c->d_afsum); (void)hipFree(c->d_fscore);
     (void)hipFree(c->d_act); (void)hipFree(c->d_st); (void)hipFree(c->d_res_idx); (void)hipFree(c->d_res_new); (void)hipFree(c->d_res_score);
