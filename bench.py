@@ -37,6 +37,8 @@ METRIC = "greedy iterations/sec + achieved HBM GB/s, 10M variants × 2.5k sample
 WORKLOADS = {
     "cfg1": ("1.1M x 2,504 (chr22-sized), select all", dict(n_var=1_103_547, n_samp=2504, select=-1)),
     "cfg1af": ("1.1M x 2,504 (chr22-sized) with float32 AF weighting, select all", dict(n_var=1_103_547, n_samp=2504, select=-1, af=True)),
+    "cfg1af64": ("1.1M x 2,504 (chr22-sized) with float64 AF values, select all",
+                 dict(n_var=1_103_547, n_samp=2504, select=-1, af=True, af_dtype="f64")),
     "cfg2": ("10M x 2,504, select all", dict(n_var=10_000_000, n_samp=2504, select=-1)),
     "cfg3": ("10M x 2,504 with float32 AF weighting, select all", dict(n_var=10_000_000, n_samp=2504, select=-1, af=True)),
     "af64": ("10M x 2,504 with float64 AF values (the reference's in-memory --af), select all",
@@ -47,7 +49,7 @@ WORKLOADS = {
     "cfg5": ("500M x 2,504 in chunks of 50M, first 10 iterations",
              dict(n_var=500_000_000, n_samp=2504, select=10, chunk_vars=50_000_000)),
 }
-ALSO = ("cfg3", "af64", "cfg1", "cfg1af", "cfg4rank", "cfg5")   # attached to the default single-GPU line, one step each
+ALSO = ("cfg3", "af64", "cfg1", "cfg1af", "cfg1af64", "cfg4rank", "cfg5")   # attached to the default single-GPU line, one step each
 
 
 def parse():
@@ -569,7 +571,7 @@ def main():
                 with m2:
                     k2 = select_count(s2)
                     cal2 = m2.stream_calibration(20 if s2["n_var"] * s2["n_samp"] < 4e11 else 3)
-                    r2 = timed_steps(m2, k2, 1, 1 if name in ("cfg1", "cfg1af", "cfg3", "af64") else 0, lambda v: v)
+                    r2 = timed_steps(m2, k2, 1, 1 if name in ("cfg1", "cfg1af", "cfg1af64", "cfg3", "af64") else 0, lambda v: v)
                     roof2 = roofline_pass(m2, k2, s2["af"])
                     if roof2 is not None:
                         roof2["stream_calibration_gbps"] = cal2

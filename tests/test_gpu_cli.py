@@ -328,8 +328,8 @@ def test_bench_default_line_carries_every_single_gpu_config(tmp_path):
     assert out.returncode == 0, out.stderr[-800:]
     j = json.loads(out.stdout.strip().splitlines()[-1])
     assert j["config"]["n_var"] == 10_000_000 and j["config"]["iterations_per_step"] == 2504 and j["exchange"] == "none"
-    assert set(j["also"]) == {"cfg3", "af64", "cfg1", "cfg1af", "cfg4rank", "cfg5"}
-    for name, want_iters in (("cfg3", 2504), ("af64", 2504), ("cfg1", 2504), ("cfg1af", 2504), ("cfg4rank", 20), ("cfg5", 10)):
+    assert set(j["also"]) == {"cfg3", "af64", "cfg1", "cfg1af", "cfg1af64", "cfg4rank", "cfg5"}
+    for name, want_iters in (("cfg3", 2504), ("af64", 2504), ("cfg1", 2504), ("cfg1af", 2504), ("cfg1af64", 2504), ("cfg4rank", 20), ("cfg5", 10)):
         e = j["also"][name]
         assert "error" not in e, e
         assert e["iterations_per_step"] == want_iters and e["value"] > 0 and e["algo_bytes_per_step"] > 0

@@ -149,3 +149,36 @@ def test_weights_with_signs_and_zeros(dev):
         if kind != "all_negative":
             state[rng.choice(n_samp, 20, replace=False)] = 2
         run_af(dev, cols, n_var, n_samp, af, state, w)
+
+
+@pytest.mark.parametrize("env", [{"UTM_PERSIST_CHAINERS": "1"}, {"UTM_PERSIST_CHAINERS": "8"}, {"UTM_PERSIST_SPEC_TICKS": "-1"},
+                                 {"UTM_PERSIST_SPEC_TICKS": "0", "UTM_PERSIST_CHAINERS": "2"}],
+                         ids=["one-chainer", "eight-chainers", "no-work-ahead", "always-ahead"])
+def test_chainer_knobs_keep_the_rows(dev, env, monkeypatch):
+    """One to eight chainer blocks, working ahead or only on request: same rows, counts and float64 scores."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(14)
+    n_var, n_samp = 90_000, 700
+    dense = rng.random((n_var, n_samp)) < 0.01
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    af = quantized_af(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    st = run_af(dev, cols, n_var, n_samp, af)
+    assert st["persist_iterations"] > 0.5 * st["iterations"], st
+
+
+def test_requests_nobody_answers_run_into_their_bounded_wait(dev, monkeypatch):
+    """Test hook UTM_PERSIST_SPEC_TICKS=-2: the chainers leave right after the census.  A pick that needs sums which are not
+    on record asks, waits its bounded time (~0.1 s), ends the launch undecided, and the host's verification launch decides:
+    the oracle's rows all the same (and launches that keep ending this way are spaced out)."""
+    monkeypatch.setenv("UTM_PERSIST_SPEC_TICKS", "-2")
+    rng = np.random.default_rng(15)
+    n_var, n_samp = 40_000, 120
+    dense = rng.random((n_var, n_samp)) < 0.02
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    dense[:, 11] = dense[:, 5]                                   # one exact tie that lasts until one of the two is picked
+    af = quantized_af(rng, n_var, n_samp)
+    cols = npo.pack_columns(dense)
+    st = run_af(dev, cols, n_var, n_samp, af)
+    assert st["persist_unresolved"] > 0 and st["persist_iterations"] > 0, st

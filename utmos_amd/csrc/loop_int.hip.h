@@ -316,6 +316,7 @@ __device__ __forceinline__ void loop_chainer(const PickArgs &a, LoopSync *sync, 
     if (threadIdx.x == 0) L->bad = 0;
     __syncthreads();
     if (!L->go) return;
+    if (iv.spec_min_ticks == -2) return;  // (test hook: chainers that are gone -- the picker's requests run into their bounded wait)
     unsigned applied = 0;  // records followed so far: priv is covered as iteration `applied` of the launch sees it
     u64 served = 0, t_last = 0;
     unsigned idle = 0, spec_budget = 0;
