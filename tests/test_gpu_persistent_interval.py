@@ -182,3 +182,19 @@ def test_requests_nobody_answers_run_into_their_bounded_wait(dev, monkeypatch):
     cols = npo.pack_columns(dense)
     st = run_af(dev, cols, n_var, n_samp, af)
     assert st["persist_unresolved"] > 0 and st["persist_iterations"] > 0, st
+
+
+@pytest.mark.parametrize("tile_kib", ["16", "32", "64"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_af_forms_with_forced_larger_tiles(dev, tile_kib, dtype, monkeypatch):
+    """By default the AF forms take the 8 KiB tile only (UTM_PERSIST_AF_MAX_TILES); UTM_PERSIST_TILE_KIB forces the
+    instantiations with tiles of several batches: same rows and scores."""
+    monkeypatch.setenv("UTM_PERSIST_TILE_KIB", tile_kib)
+    rng = np.random.default_rng(int(tile_kib))
+    n_var, n_samp = 400_000, 150
+    dense = rng.random((n_var, n_samp)) < 0.02
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    af = quantized_af(rng, n_var, n_samp) if dtype == "f64" else (rng.integers(1, 2 * n_samp, n_var) / (2.0 * n_samp)).astype(np.float32)
+    cols = npo.pack_columns(dense)
+    st = run_af(dev, cols, n_var, n_samp, af)
+    assert st["persist_iterations"] > 0.5 * st["iterations"], st

@@ -205,6 +205,11 @@ static LoopShape loop_shape(utm_ctx *c, int af = 0)
         if (tn.persist_tile_kib > 0 && steps != tn.persist_tile_kib) continue;
         const u64 tiles = (steps_total + steps - 1) / steps;
         if (tiles > (u64)std::max(1, tn.persist_max_tiles) && tn.persist_tile_kib <= 0) continue;
+        // The AF forms: the one-batch tile only, and fewer tiles -- their workers keep two tiles in LDS and gather, their
+        // words travel in pairs.  Measured against the launches (2,504 samples, float32 / float64 AF): 17 tiles +23 % /
+        // +22 %, 24 tiles +7 % / +6 %, 28 tiles . / -1 %, 31 tiles -1.5 % / -5 %; 16 KiB tiles (3M x 640) +2 % / -13 %;
+        // 64 KiB tiles (10M x 313) -50 % / -51 %.
+        if (af && tn.persist_tile_kib <= 0 && (steps > 8 || tiles > (u64)std::max(1, tn.persist_af_max_tiles))) break;
         // tiles of several batches only pay where the launch per iteration is weak -- few samples, tall columns (10M x 313:
         // +12 %); with 2,504 samples they lose ~10 % to the one-batch tile at equal height (1.1M: 0.70 against 0.79) and
         // are level with the launches at best (3M: +2 % / -3.4 %)

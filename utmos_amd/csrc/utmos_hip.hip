@@ -126,7 +126,7 @@ struct Tune {
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
-    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, persist_tall_max_samples, persist_af, persist_af_interval, persist_spec_ticks, persist_chainers, test_drop_arrival;
+    int persistent, persist_max_mb, persist_wgs_per_cu, persist_claims, persist_ahead_ticks, persist_ahead0_ticks, persist_max_tiles, persist_tile_kib, persist_max_samples, persist_tall_max_samples, persist_af, persist_af_max_tiles, persist_af_interval, persist_spec_ticks, persist_chainers, test_drop_arrival;
     int mbox_spins_log2, test_mute_exchange;                                 // mailbox exchange: patience, test hook   // persistent loop kernel
 };
 struct KnobDef {
@@ -167,6 +167,7 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_PERSIST_TALL_MAX_SAMPLES", persist_tall_max_samples, 640),  // tiles of several batches (columns taller than 32 x 8 KiB) only up to this many samples
     UTM_KNOB_I("UTM_PERSIST_MAX_SAMPLES", persist_max_samples, 2560),  // (one chunk of count words for the picker: UTM_LOOP_THREADS x UTM_LOOP_E)
     UTM_KNOB_I("UTM_PERSIST_AF", persist_af, 1),  // the AF form (exact float32 phase) of the persistent loop
+    UTM_KNOB_I("UTM_PERSIST_AF_MAX_TILES", persist_af_max_tiles, 26),  // ... both AF forms: 8 KiB tiles only, at most this many (taller matrices keep the launches)
     UTM_KNOB_I("UTM_PERSIST_SPEC_TICKS", persist_spec_ticks, 1000),  // interval form: the chainer works ahead (one chain per record) while iterations take longer than this many 10 ns ticks -- a request waits for a chain in progress; -1: never; -2 (test hook): the chainers leave at once, every request times out and the host decides
     UTM_KNOB_I("UTM_PERSIST_CHAINERS", persist_chainers, 4),  // interval form: blocks that keep sequential float64 sums on record (1..8; a request for 2 x this many samples is served in one go)
     UTM_KNOB_I("UTM_PERSIST_AF_INTERVAL", persist_af_interval, 1),  // ... and its interval form (float64 AF values; float32 sums outside the exact range): candidates and chains inside the picker
