@@ -45,7 +45,7 @@
  *   UTM_DECR_FIRST_BATCH (8), UTM_DECR_INTERLEAVED (1)                      decremental mode: first batch size, second copy on/off
  *   UTM_P2P_REPLICATE (1)     copy the peers' columns once (0: read winners in place over the mappings)
  *   UTM_TEST_REMOTE_WINNER (0) test hook: read local winners from the exchange's winner-column buffer too
- *   UTM_PERSISTENT (1)        unweighted integer scores (and float32 AF once its sums are exact), one chunk, the only shard: a
+ *   UTM_PERSISTENT (1)        integer scores (weighted or not) and the verified-parallel AF forms, one chunk, the only shard: a
  *                             batch of iterations as ONE persistent
  *                             launch (k_loop_int: workers keep their covered tile in LDS, the picker's record replaces the kernel
  *                             boundary, two batches per wave run ahead across the hand-off)
@@ -55,7 +55,12 @@
  *   UTM_PERSIST_WGS_PER_CU (0 = what the occupancy query allows)   resident 512-thread blocks per CU the grid is sized for
  *   UTM_PERSIST_AHEAD_TICKS (400), UTM_PERSIST_AHEAD0_TICKS (0)    10 ns ticks before the next record is due at which a wave requests
  *                             its second / first run-ahead batch (0: as soon as it runs out of work)
- *   UTM_PERSIST_AF (1)        float32 AF, exact fixed-point phase: the delta iterations run inside the persistent loop too
+ *   UTM_PERSIST_AF (1)        AF scores: the delta iterations run inside the persistent loop too -- float32 AF in its exact fixed-point
+ *                             phase, and (UTM_PERSIST_AF_INTERVAL, 1) float64 AF / float32 sums outside the exact range with score intervals:
+ *                             the picker lists the candidates, UTM_PERSIST_CHAINERS (4, 1..8) blocks at the end of the grid keep their
+ *                             sequential float64 sums on record, working ahead while iterations take longer than UTM_PERSIST_SPEC_TICKS
+ *                             (1000 x 10 ns; -1: only on request; -2: test hook, the chainers leave and every request times out).
+ *                             Both AF forms: 8 KiB tiles only, at most UTM_PERSIST_AF_MAX_TILES (26)
  *   UTM_PERSIST_CLAIMS (1)    positions behind a wave's two static ones are claimed from per-tile counters (0: dealt statically)
  *   UTM_MBOX_SPINS_LOG2 (24)  mailbox exchange: polls (x ~0.5 us) before a peer's record is declared lost (UTM_ECOMM)
  *   UTM_TEST_MUTE_EXCHANGE (0) test hook: in that iteration since the reset this shard posts no record into the mailboxes
