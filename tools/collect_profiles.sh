@@ -32,6 +32,9 @@ echo "== per-iteration cost of every exchange form, from one GPU (10M x 313 = on
 (cd $R && AB_REPS=1 AB_STEPS=2 bash tools/exchange_table.sh "--n-var 10000000 --n-samp 2504" > $out/${tag}_exchange_cost_one_gpu_cfg2.txt 2>&1)
 echo "== persistent loop vs one launch per iteration over matrix heights (same box)"
 (cd $R && bash tools/ab_sizes.sh "100000 300000 600000 1103547 1500000 2000000 3000000 5000000" > $out/${tag}_persistent_vs_launches_by_height.txt 2>&1)
+echo "== the AF forms of the persistent loop vs one launch per iteration over shapes (same box)"
+(cd $R && bash tools/ab_interval.sh "300000x2504 1103547x2504 1500000x2504 2000000x2504" f32 > $out/${tag}_af_forms_vs_launches.txt 2>/dev/null)
+(cd $R && bash tools/ab_interval.sh "300000x2504 1103547x2504 1500000x2504 2000000x2504" f64 >> $out/${tag}_af_forms_vs_launches.txt 2>/dev/null)
 echo "== float64 AF (the reference's in-memory --af values)"
 python3 $R/bench.py --af --af-dtype f64 --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_bench.json 2>/dev/null
 python3 $R/bench.py --workload af64 --af-estimate-scores --steps 3 --warmup 1 --no-cpu-baseline --pmc-traffic off > $out/${tag}_af64_cli_mode_bench.json 2>/dev/null
