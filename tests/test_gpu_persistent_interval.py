@@ -198,3 +198,51 @@ def test_af_forms_with_forced_larger_tiles(dev, tile_kib, dtype, monkeypatch):
     cols = npo.pack_columns(dense)
     st = run_af(dev, cols, n_var, n_samp, af)
     assert st["persist_iterations"] > 0.5 * st["iterations"], st
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_shapes_states_weights_and_cuts(dev, seed):
+    """Random small cases through the interval form: shape, density, tie-prone or full-mantissa AF values, float32 values on
+    a coarse unit, used / excluded samples, signed weights, estimated scores, runs cut at random rows."""
+    rng = np.random.default_rng(1000 + seed)
+    n_var = int(rng.integers(2_000, 160_000))
+    n_samp = int(rng.integers(2, 700))
+    dense = rng.random((n_var, n_samp)) < rng.uniform(0.002, 0.08)
+    if rng.random() < 0.7:
+        dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    if n_samp > 4 and rng.random() < 0.5:
+        dense[:, 1] = dense[:, n_samp - 1]                      # twins
+    kind = rng.integers(0, 3)
+    if kind == 0:
+        af = quantized_af(rng, n_var, n_samp)
+    elif kind == 1:
+        af = rng.random(n_var) * 0.5 + 1e-4                     # full 53-bit mantissas
+    else:
+        af = np.exp2(rng.uniform(-36, -1, n_var)).astype(np.float32)
+    state = rng.choice([0, 1, 1, 1, 1, 2], n_samp).astype(np.uint8)
+    w = rng.choice([-1.0, 0.0, 0.5, 1.0, 1.0, 2.0], n_samp) if rng.random() < 0.4 else None
+    exact = bool(rng.random() < 0.6)
+    pieces = None
+    if rng.random() < 0.5:
+        pieces = sorted(int(x) for x in rng.integers(1, max(2, n_samp), 3)) + [n_samp]
+    cols = npo.pack_columns(dense)
+    run_af(dev, cols, n_var, n_samp, af, state, w, pieces, exact, estimate_rtol=None if kind == 2 else 1e-6)
+
+
+def test_chr22_sized_float64_af_first_rows_against_the_oracle(dev):
+    """1,103,547 x 2,504 (BASELINE configs[0]'s size) with float64 AF values, the synthetic matrix of bench.py's cfg1af64: the
+    first 700 rows -- the launch path's dense passes, then persistent launches with their first ties -- against the OpenMP
+    C oracle on the matrix downloaded from the device; rows, counts and float64 scores bit for bit."""
+    n_var, n_samp, k = 1_103_547, 2504, 700
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.synth_fill(c, seed=0)
+        cols = m.download_columns(c)
+        _, af = dev.synth_host(0, n_var, n_samp, want_cols=False)
+        af64 = af.astype(np.float64) / 3.0
+        m.set_af(c, af64)
+        got = m.run(k)
+        st = m.stats()
+    exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8), af=af64, k_max=k, omp=True)
+    assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
+    assert st["persist_iterations"] > 600 and st["af_deferred_rows"] > 0, st
