@@ -231,9 +231,9 @@ def test_random_shapes_states_weights_and_cuts(dev, seed):
 
 def test_chr22_sized_float64_af_first_rows_against_the_oracle(dev):
     """1,103,547 x 2,504 (BASELINE configs[0]'s size) with float64 AF values, the synthetic matrix of bench.py's cfg1af64: the
-    first 700 rows -- the launch path's dense passes, then persistent launches with their first ties -- against the OpenMP
+    first 300 rows -- the launch path's dense passes, then persistent launches with their first ties -- against the OpenMP
     C oracle on the matrix downloaded from the device; rows, counts and float64 scores bit for bit."""
-    n_var, n_samp, k = 1_103_547, 2504, 700
+    n_var, n_samp, k = 1_103_547, 2504, 300
     with dev.DeviceMatrix(n_samp) as m:
         c = m.add_chunk(n_var)
         m.synth_fill(c, seed=0)
@@ -245,4 +245,4 @@ def test_chr22_sized_float64_af_first_rows_against_the_oracle(dev):
         st = m.stats()
     exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8), af=af64, k_max=k, omp=True)
     assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist() and got[2].tolist() == exp[2].tolist()
-    assert st["persist_iterations"] > 600 and st["af_deferred_rows"] > 0, st
+    assert st["persist_iterations"] > 200 and st["af_deferred_rows"] > 0, st
