@@ -54,7 +54,7 @@ struct LoopSync {
     unsigned go;              // the picker's census verdict: 1 go, 2 abort
     unsigned worker_timeout;  // a worker gave up waiting for a record (diagnostic)
     // interval form: the picker's request to the chainer blocks -- sums on record for these samples, please (chainer j
-    // takes samples 2j and 2j + 1)
+    // takes the samples s with s % n_chainers == j)
     unsigned req_s[2 * UTM_LOOP_MAX_CHAINERS];
     unsigned pad1[30 - 2 * UTM_LOOP_MAX_CHAINERS];
     u64 req_hdr;              // id << 8 | number of samples; id = epoch << 8 | round within the iteration (written last)
@@ -368,14 +368,17 @@ __device__ __forceinline__ void loop_chainer(const PickArgs &a, LoopSync *sync, 
         const u64 id = req >> 8;
         if (id != served && (id >> 8) == (u64)applied + 1) {
             // the picker is waiting: these samples' sums, two at a time
-            const unsigned n = (unsigned)(req & 0xFFu), i = 2 * iv.chainer;
-            if (i < n) {
-                const unsigned s0 = __hip_atomic_load(&sync->req_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool two = i + 1 < n;
-                const unsigned s1 = two ? __hip_atomic_load(&sync->req_s[i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : s0;
-                loop_chain2(a, iv, L, s0, s1, two);
-                if (threadIdx.x == 0) __hip_atomic_store(&sync->req_done[iv.chainer], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ... those of this chainer's residue class: a sample's record has ONE writer, whoever asks and whenever (two
+            // chainers at different points of the record log writing the same sample's sum and count could interleave
+            // into a pair that matches the picker's count with the other's sum)
+            const unsigned n = (unsigned)(req & 0xFFu);
+            unsigned mine[2 * UTM_LOOP_MAX_CHAINERS], n_mine = 0;
+            for (unsigned i = 0; i < n && i < 2 * UTM_LOOP_MAX_CHAINERS; ++i) {
+                const unsigned rs = __hip_atomic_load(&sync->req_s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (rs % iv.n_chainers == iv.chainer) mine[n_mine++] = rs;
             }
+            for (unsigned i = 0; i < n_mine; i += 2) loop_chain2(a, iv, L, mine[i], i + 1 < n_mine ? mine[i + 1] : mine[i], i + 1 < n_mine);
+            if (threadIdx.x == 0) __hip_atomic_store(&sync->req_done[iv.chainer], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             served = id;
             idle = 0;
             continue;
@@ -697,16 +700,16 @@ __device__ __forceinline__ void loop_picker(const PickArgs &a, LoopSync *sync, u
                         }
                         todo_before = todo;
                         asked = true;
-                        // the first two per chainer still missing: to the chainers
+                        // the first 16 still missing: to the chainers (each takes its residue class of samples)
                         const u64 id = ((u64)((unsigned)k + 1) << 8) | (u64)(round & 0xFFu);
                         if (threadIdx.x == 0) {
                             unsigned n = 0;
-                            for (u64 t = todo; t && n < 2 * iv.n_chainers; t &= t - 1, ++n)
+                            for (u64 t = todo; t && n < 2 * UTM_LOOP_MAX_CHAINERS; t &= t - 1, ++n)
                                 __hip_atomic_store(&sync->req_s[n], L->cand[__builtin_ctzll(t)].s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                             __hip_atomic_store(&sync->req_hdr, (id << 8) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             bool ok = true;
-                            for (unsigned j = 0; 2 * j < n && ok; ++j) {
+                            for (unsigned j = 0; j < iv.n_chainers && ok; ++j) {
                                 ok = false;
                                 for (unsigned spin = 0; spin < UTM_LOOP_REQ_SPINS; ++spin) {
                                     if (__hip_atomic_load(&sync->req_done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == id) { ok = true; break; }
