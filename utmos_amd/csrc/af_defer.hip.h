@@ -22,7 +22,8 @@ struct DeferArgs {
     const SeqChunk *chunks;  // af / w per chunk
     const ChainSeg *segs;
     int n_segs;
-    const u64 *log;          // [UTM_DEFER_SLOTS][col_words]: row r's mask in slot r % UTM_DEFER_SLOTS
+    const u64 *log;          // [slots][col_words]: row r's mask in slot r % slots
+    int slots;
     u64 col_words;
     unsigned *counts;        // [n_rows][n_segs]
     u64 *offs;               // [n_rows * n_segs + 1]
@@ -33,17 +34,17 @@ struct DeferArgs {
 
 __device__ __forceinline__ const u64 *defer_mask(const DeferArgs &d, int row_i, const ChainSeg &sg)
 {
-    return d.log + (u64)((d.row0 + row_i) % UTM_DEFER_SLOTS) * d.col_words + sg.off;
+    return d.log + (u64)((d.row0 + row_i) % d.slots) * d.col_words + sg.off;
 }
 
 // The mask of the LAST row of a run: no later pass made it (utm_run's end).  Does not touch covered.
 __global__ __launch_bounds__(256) void k_newly_log(const u64 *__restrict__ covered, const u64 *__restrict__ cols, u64 wp,
                                                    const Pending pend, const IterState *__restrict__ st, u64 *__restrict__ log_chunk,
-                                                   u64 col_words)
+                                                   u64 col_words, int slots)
 {
     const u64 *wcol = pending_column(st, cols, wp, pend);
     if (!wcol || st->iter < 1) return;
-    u64 *out = log_chunk + (u64)((st->iter - 1) % UTM_DEFER_SLOTS) * col_words;
+    u64 *out = log_chunk + (u64)((st->iter - 1) % slots) * col_words;
     for (u64 w = (u64)blockIdx.x * 256 + threadIdx.x; w < wp; w += (u64)gridDim.x * 256) out[w] = wcol[w] & ~covered[w];
 }
 

@@ -93,7 +93,7 @@ static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub, bo
                           ch.covered, ch.wp, ch.afx, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,
                           group, n_groups, delta_fold ? ch.covered_alt : nullptr,
                           (delta_fold && defer_active(c) && c->enq_iter > 0)
-                              ? c->d_newly_log + (u64)((c->enq_iter - 1) % UTM_DEFER_SLOTS) * c->col_words + ch.off : nullptr);
+                              ? c->d_newly_log + (u64)((c->enq_iter - 1) % c->defer_slots) * c->col_words + ch.off : nullptr);
 }
 
 // The streaming kernels (k_score_int, k_score_afs): grid = variant tiles x groups of samples.  Tile = the largest
@@ -132,7 +132,7 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
                           ch.covered, ch.wp, afb, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum,   \
                           (unsigned)group, n_groups, (delta && !fold) ? ch.mask : nullptr, (delta && fold) ? ch.covered_alt : nullptr, \
                           (delta && fold && defer_active(c) && c->enq_iter > 0)                                                       \
-                              ? c->d_newly_log + (u64)((c->enq_iter - 1) % UTM_DEFER_SLOTS) * c->col_words + ch.off : nullptr)
+                              ? c->d_newly_log + (u64)((c->enq_iter - 1) % c->defer_slots) * c->col_words + ch.off : nullptr)
         if (steps == 32) UTM_LAUNCH_AFS(32, 8);  // second argument: queue depth per lane
         else if (steps == 16) UTM_LAUNCH_AFS(16, 16);
         else if (steps == 8) UTM_LAUNCH_AFS(8, 16);
@@ -285,7 +285,7 @@ static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch, int af = 0
     LaunchTimer t(c);
     const LoopAf laf{af ? ch.afx : nullptr, af ? c->d_loop_w[2] : nullptr, af ? c->d_loop_w[3] : nullptr,
                      af == 2 ? ch.af : nullptr, af == 2 ? c->d_loop_priv : nullptr,
-                     (af == 2 && defer_active(c)) ? c->d_newly_log + ch.off : nullptr, c->col_words, c->tune.persist_spec_ticks, n_chainers};
+                     (af == 2 && defer_active(c)) ? c->d_newly_log + ch.off : nullptr, c->col_words, c->defer_slots, c->tune.persist_spec_ticks, n_chainers};
     u64 *w0 = af ? c->d_loop_w[0] : c->d_cnt, *w1 = af ? c->d_loop_w[1] : c->d_cnt_alt;  // (AF: d_cnt holds the per-sample counts)
     if (getenv("UTM_VERBOSE") && c->persist_launches == 0)
         fprintf(stderr, "libutmos_hip: k_loop_int form %d: cols %p..%p covered %p priv %p (wp %llu) af %p afx %p log %p (stride %llu) known %p %p words %p %p %p %p act %p cnt %p afsum %p sync %p claim %p grid %u\n",
@@ -577,12 +577,13 @@ static int collect_event_times(utm_ctx *c)
 static int defer_finish_rows(utm_ctx *c, i64 lo, i64 hi)
 {
     if (hi <= lo) return UTM_OK;
-    if (hi - lo > UTM_DEFER_SLOTS) return fail(UTM_ESTATE, "deferred scores: %lld rows in one go (internal error)", (long long)(hi - lo));
+    if (hi - lo > c->defer_slots) return fail(UTM_ESTATE, "deferred scores: %lld rows in one go (internal error)", (long long)(hi - lo));
     DeferArgs d;
     d.chunks = c->d_seq;
     d.segs = c->d_segs;
     d.n_segs = c->chain_fast.n_segs;
     d.log = c->d_newly_log;
+    d.slots = c->defer_slots;
     d.col_words = c->col_words;
     d.counts = c->d_defer_counts;
     d.offs = c->d_defer_offs;
@@ -609,7 +610,7 @@ static int defer_flush_last(utm_ctx *c)
     if (c->defer_lo >= c->iter) return UTM_OK;
     for (auto &ch : c->chunks)
         hipLaunchKernelGGL(k_newly_log, dim3((unsigned)std::min<u64>(1024, (ch.wp + 255) / 256)), dim3(256), 0, c->stream, ch.covered, ch.cols,
-                           ch.wp, pending_of(c, ch, false), (const IterState *)c->d_st, c->d_newly_log + ch.off, c->col_words);
+                           ch.wp, pending_of(c, ch, false), (const IterState *)c->d_st, c->d_newly_log + ch.off, c->col_words, c->defer_slots);
     return defer_finish_rows(c, c->defer_lo, c->iter);
 }
 
@@ -632,7 +633,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
     int batch = rccl_needs_root(c) ? 1 : batch_env > 0 ? batch_env : c->af_mode != UTM_AF_NONE ? 64 : 256;
     // deferred exact AF scores log one newly-covered mask per row of a batch in UTM_DEFER_SLOTS slots (row % slots):
     // a longer batch would overwrite masks that are not finished yet
-    if (c->af_mode != UTM_AF_NONE && c->af_fixed && defer_active(c)) batch = std::min(batch, (int)UTM_DEFER_SLOTS);
+    if (c->af_mode != UTM_AF_NONE && c->af_fixed && defer_active(c)) batch = std::min(batch, c->defer_slots);
     if (c->af_mode == UTM_AF_NONE) batch = std::min(batch, 256);  // (the persistent loop's record carries an 8-bit iteration tag)
     i64 enq = 0;
     bool tail_deferred = false;  // the last batch left its last row's exact score to the end of the run
@@ -645,7 +646,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         // (interval form with deferred exact scores: a launch logs one newly-covered mask per row, UTM_DEFER_SLOTS slots)
         const i64 this_batch = c->loop_unresolved                                             ? 1
                                : c->persist_backoff > 0                                       ? std::min<i64>(batch, c->persist_backoff)
-                               : loop_af_batch                                                ? ((form_hint == 2 && defer_active(c)) ? (i64)UTM_DEFER_SLOTS : 256)
+                               : loop_af_batch                                                ? ((form_hint == 2 && defer_active(c)) ? (i64)c->defer_slots : 256)
                                : (c->af_mode != UTM_AF_NONE && c->af_fixed && c->iter < 64) ? std::min<i64>(batch, c->iter < 8 ? 4 : 8)
                                : (c->decr_enabled && c->iter < 64)                          ? std::min<i64>(batch, decr_first)
                                                                                             : batch;
@@ -680,7 +681,7 @@ extern "C" int utm_run(utm_ctx *c, int64_t k_max, int64_t *idx_out, int64_t *new
         const int loop_af = (af_par && !verify_only) ? loop_af_form(c, first_is_full) : 0;
         const LoopShape loop = (!decr && !verify_only && fuse_mode == 1 && c->tune.fuse_pick && (c->af_mode == UTM_AF_NONE || loop_af)) ? loop_shape(c, loop_af) : LoopShape();
         if (loop.ok) n = std::min<i64>(n, 256);  // (a launch's record carries an 8-bit iteration tag; UTM_BATCH may ask for more)
-        if (loop.ok && loop_af == 2 && defer_active(c)) n = std::min<i64>(n, UTM_DEFER_SLOTS);
+        if (loop.ok && loop_af == 2 && defer_active(c)) n = std::min<i64>(n, c->defer_slots);
         if (loop.ok) TRY(enqueue_loop(c, loop, (int)n, loop_af));
         for (i64 j = 0; j < n && !loop.ok; ++j) {
             bool picked = false;

@@ -225,13 +225,16 @@ static int build_af_tables(utm_ctx *c)
         const int defer_env = c->tune.af_defer;
         u64 slots = 0;  // addend slots: every word that holds variants
         for (auto &ch : c->chunks) slots += ch.w * 64;
-        const size_t need = (size_t)UTM_DEFER_SLOTS * c->col_words * 8 + slots * 8 + (size_t)UTM_DEFER_SLOTS * n * 12 + 8;
+        // (a whole persistent batch of rows where the matrix is one the persistent loop takes, else the launches' 64)
+        const bool small = c->chunks.size() == 1 && c->tune.persist_max_mb > 0 && (u64)c->n_local * c->col_words * 8 <= ((u64)c->tune.persist_max_mb << 20);
+        c->defer_slots = small ? UTM_DEFER_SLOTS : UTM_DEFER_SLOTS_LAUNCHES;
+        const size_t need = (size_t)c->defer_slots * c->col_words * 8 + slots * 8 + (size_t)c->defer_slots * n * 12 + 8;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         if (defer_env && cap && c->d_segs && c->n_local == c->n_total && slots < 0xFFFF0000ull && need <= free_b / 4) {
-            const bool ok = hipMalloc(&c->d_newly_log, (size_t)UTM_DEFER_SLOTS * c->col_words * 8) == hipSuccess &&
+            const bool ok = hipMalloc(&c->d_newly_log, (size_t)c->defer_slots * c->col_words * 8) == hipSuccess &&
                             hipMalloc(&c->d_defer_vals, slots * 8) == hipSuccess &&
-                            hipMalloc(&c->d_defer_counts, (size_t)UTM_DEFER_SLOTS * n * 4) == hipSuccess &&
-                            hipMalloc(&c->d_defer_offs, ((size_t)UTM_DEFER_SLOTS * n + 1) * 8) == hipSuccess;
+                            hipMalloc(&c->d_defer_counts, (size_t)c->defer_slots * n * 4) == hipSuccess &&
+                            hipMalloc(&c->d_defer_offs, ((size_t)c->defer_slots * n + 1) * 8) == hipSuccess;
             if (!ok) {  // all four or none (defer_active looks at the log alone)
                 (void)hipGetLastError();
                 (void)hipFree(c->d_newly_log); (void)hipFree(c->d_defer_counts); (void)hipFree(c->d_defer_offs); (void)hipFree(c->d_defer_vals);

@@ -169,6 +169,7 @@ struct LoopAf {
     u64 *priv;               // the picker's own copy of `covered`, kept current (the chunk's second covered buffer)
     u64 *newly_log;          // deferred exact scores: the log of newly-covered masks (af_defer.hip.h), or nullptr
     u64 log_stride;          // words between two slots of the log
+    int log_slots;           // slots of the log (row r: slot r % log_slots)
     int spec_min_ticks;      // the chainers work ahead while iterations take longer than this (10 ns ticks; < 0: never)
     int n_chainers;          // 1..UTM_LOOP_MAX_CHAINERS blocks at the end of the grid; priv holds one covered mask for each
 };
@@ -1011,7 +1012,7 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, AFM == 2 ? UTM_LOOP_IV_BLOCKS : 4
         // Deferred exact scores (af_defer.hip.h): what a row's winner newly covered is what its float64 score runs over --
         // the mask goes into the row's slot of the log, as from a delta pass of k_score_afs (row = the pending winner's)
         if (AFM == 2 && laf.newly_log && slot == 0 && wcol && iter0 >= 1) {
-            v4u *lg = reinterpret_cast<v4u *>(laf.newly_log + (u64)((iter0 - 1) % UTM_DEFER_SLOTS) * laf.log_stride + w0);
+            v4u *lg = reinterpret_cast<v4u *>(laf.newly_log + (u64)((iter0 - 1) % laf.log_slots) * laf.log_stride + w0);
             for (int k = threadIdx.x; k < nsteps * 64; k += UTM_LOOP_THREADS) lg[k] = wc[k] & ~cv[k];
         }
     }
@@ -1242,7 +1243,7 @@ __global__ __launch_bounds__(UTM_LOOP_THREADS, AFM == 2 ? UTM_LOOP_IV_BLOCKS : 4
         {
             const v4u *wc = reinterpret_cast<const v4u *>(cols + (u64)r.winner * wp + w0);
             v4u *lg = (AFM == 2 && laf.newly_log && slot == 0)
-                          ? reinterpret_cast<v4u *>(laf.newly_log + (u64)((iter0 + k) % UTM_DEFER_SLOTS) * laf.log_stride + w0) : nullptr;
+                          ? reinterpret_cast<v4u *>(laf.newly_log + (u64)((iter0 + k) % laf.log_slots) * laf.log_stride + w0) : nullptr;
             for (int kk = threadIdx.x; kk < nsteps * 64; kk += UTM_LOOP_THREADS) {
                 const v4u w = wc[kk], l = live[kk];
                 if (AF) newly_lds[kk] = l & w;

@@ -22,7 +22,8 @@ __device__ __forceinline__ u64 af_fixed(unsigned f)
 // a * 2^q = af_fixed(table entry).
 // ------------------------------------------------------------------------------------------------
 #define UTM_AF_TILE_WORDS 128
-#define UTM_DEFER_SLOTS 256  // iterations whose newly-covered masks the log holds (af_defer.hip.h): a whole batch of the persistent loop
+#define UTM_DEFER_SLOTS 256  // most iterations whose newly-covered masks the log holds (af_defer.hip.h): a whole batch of the persistent loop;
+#define UTM_DEFER_SLOTS_LAUNCHES 64  // ... and what a context gets whose matrix keeps the launches (utm_ctx::defer_slots)
 // covered_out != nullptr: a *delta* pass as in k_score_afs below -- the tile's mask is what the pending winner newly
 // covers, the shares are subtracted, group 0 writes covered | winner into the other buffer of the pair (and the mask
 // into the log of af_defer.hip.h).  The form for the first iterations of a run, when a winner still newly covers

@@ -282,7 +282,8 @@ struct utm_ctx {
     ChainFast chain_fast{nullptr, 0, nullptr, nullptr, 0, 0};  // device buffers of the chains' fast path
     ChainSeg *d_segs = nullptr;
     // deferred exact AF scores (af_defer.hip.h): the log of newly-covered masks and the finishing launches' buffers
-    u64 *d_newly_log = nullptr;       // [UTM_DEFER_SLOTS][col_words], or null (no room / not the only shard's AF loop)
+    u64 *d_newly_log = nullptr;       // [defer_slots][col_words], or null (no room / not the only shard's AF loop)
+    int defer_slots = UTM_DEFER_SLOTS_LAUNCHES;  // 256 where the persistent loop may take the matrix (a launch logs a whole batch), else 64
     unsigned *d_defer_counts = nullptr;
     u64 *d_defer_offs = nullptr;
     double *d_defer_vals = nullptr;
