@@ -132,6 +132,7 @@ typedef struct utm_stats {
     int64_t persist_launches;      /* such launches since the last utm_reset (each counts once in score_launches) */
     int64_t persist_iterations;    /* rows they produced (0: every iteration was a launch of its own) */
     int64_t persist_unresolved;    /* launches (interval form of the AF loop) that left their last iteration to a verification launch */
+    int64_t af_table_passes;       /* full dense AF passes (one per chunk) that ran as table lookups (k_score_aft) since the last utm_reset */
 } utm_stats;
 
 /* utm_stats.exchange */

@@ -30,7 +30,7 @@ def test_abi_version_and_struct_sizes():
     from utmos_amd import _native as nat
     assert nat.lib().utm_abi_version() == 3
     assert ctypes.sizeof(nat.Record) == 64
-    assert ctypes.sizeof(nat.Stats) == 8 * 6 + 4 * 4 + 8 * 4 + 4 * 2 + 8 * 5
+    assert ctypes.sizeof(nat.Stats) == 8 * 6 + 4 * 4 + 8 * 4 + 4 * 2 + 8 * 6
 
 
 def test_argument_errors_are_reported_without_a_gpu():

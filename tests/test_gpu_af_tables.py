@@ -1,0 +1,89 @@
+"""The full dense AF pass as table lookups (k_score_aft, score_af.hip.h) against the CPU oracle: rows, counts and
+float64 scores of whole runs, with the table kernel (UTM_AF_TABLES=1,
+the default) and with the bit-walking kernel it replaces (k_score_afq, UTM_AF_TABLES=0).  Reference arithmetic:
+utmos/select.py:36-48 (row value added to every carrier of an uncovered row; first maximum wins)."""
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from test_gpu_parity import check_run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from utmos_amd import _native as nat
+    assert nat.device_count() >= 1, "no GPU visible"
+    from utmos_amd import device
+    return device
+
+
+def _af_of(dense, n_samp, kind):
+    af = np.maximum(dense.sum(axis=1), 1) / (2.0 * n_samp)
+    return af.astype(np.float32) if kind == "f32" else af / 3.0
+
+
+@pytest.mark.parametrize("tables", ["1", "0"])
+@pytest.mark.parametrize("n_samp", [64, 65, 131, 300])
+def test_select_all_checks_every_samples_first_pass_sum(dev, tables, n_samp, monkeypatch):
+    """float32 AF in the exact range: a winner's reported score IS its accumulator (first full pass minus the delta
+    passes' exact decreases), so a select-all run compares every sample's first-pass sum with the oracle, bit for bit."""
+    monkeypatch.setenv("UTM_AF_TABLES", tables)
+    rng = np.random.default_rng(1000 + n_samp)
+    n_var = 2048 * 5 + 777                      # ragged last tile of the 2,048-variant table tiles
+    dense = ou.random_dense(rng, n_var, n_samp)
+    af = _af_of(dense, n_samp, "f32")
+    af[::53] = 0.0
+    state = np.ones(n_samp, np.uint8)
+    state[3] = 2                                # excluded
+    state[n_samp - 1] = 0                       # already used: its variants start out covered
+    got, st = check_run(dev, dense, state=state, af=af)
+    assert len(got[0]) > n_samp // 2
+    assert st["af_table_passes"] == (1 if tables == "1" else 0), st
+
+
+@pytest.mark.parametrize("tables", ["1", "0"])
+@pytest.mark.parametrize("kind", ["f32", "f64", "f32_chunks", "f32_weights"])
+def test_runs_with_the_table_pass(dev, tables, kind, monkeypatch):
+    monkeypatch.setenv("UTM_AF_TABLES", tables)
+    rng = np.random.default_rng(77)
+    n_var, n_samp = 2048 * 11 + 5, 150
+    dense = ou.random_dense(rng, n_var, n_samp)
+    af = _af_of(dense, n_samp, "f64" if kind == "f64" else "f32")
+    w = rng.choice([0.5, 1.0, 2.0], n_samp) if kind == "f32_weights" else None
+    chunks = [0, 2048 * 3 + 100, 2048 * 7, n_var] if kind == "f32_chunks" else None
+    _, st = check_run(dev, dense, af=af, weights=w, chunks=chunks)
+    n_chunks = 3 if chunks else 1
+    assert st["af_table_passes"] == (n_chunks if tables == "1" else 0), st
+
+
+def test_more_samples_than_one_group_holds(dev):
+    """Above 1,024 samples the sample axis is cut into groups (a group's list sits in LDS)."""
+    rng = np.random.default_rng(5)
+    n_var, n_samp = 2048 * 2 + 64, 1100
+    dense = rng.random((n_var, n_samp)) < 0.02
+    dense[np.arange(n_var), rng.integers(0, n_samp, n_var)] = True
+    af = _af_of(dense, n_samp, "f32")
+    _, st = check_run(dev, dense, af=af)
+    assert st["af_table_passes"] == 1, st
+
+
+def test_values_too_wide_for_the_limbs_keep_the_bit_walking_kernel(dev):
+    """Exponents spread over more than 22 bits: a table value could pass 2^46 units, k_score_aft is not admitted."""
+    rng = np.random.default_rng(6)
+    n_var, n_samp = 9000, 80
+    dense = ou.random_dense(rng, n_var, n_samp)
+    af = (2.0 ** -rng.integers(1, 30, n_var)).astype(np.float32)
+    _, st = check_run(dev, dense, af=af, k=20)
+    assert st["af_table_passes"] == 0, st
+
+
+def test_dense_columns(dev):
+    """Every nibble value occurs: half of all cells set."""
+    rng = np.random.default_rng(8)
+    n_var, n_samp = 2048 * 3, 96
+    dense = rng.random((n_var, n_samp)) < 0.5
+    af = _af_of(dense, n_samp, "f32")
+    _, st = check_run(dev, dense, af=af, k=10)
+    assert st["af_table_passes"] == 1, st

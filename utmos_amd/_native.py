@@ -37,7 +37,8 @@ class Stats(ctypes.Structure):
                 ("exchange", ctypes.c_int32), ("rccl_ranks", ctypes.c_int32),
                 ("af_chained_iterations", ctypes.c_int64), ("af_deferred_rows", ctypes.c_int64),
                 ("persist_launches", ctypes.c_int64), ("persist_iterations", ctypes.c_int64),
-                ("persist_unresolved", ctypes.c_int64)]
+                ("persist_unresolved", ctypes.c_int64),
+                ("af_table_passes", ctypes.c_int64)]
 
 
 EXCHANGE_NAMES = {0: "none", 1: "mailboxes", 2: "rccl", 3: "caller-driven", 4: "rccl-allreduce"}

@@ -83,6 +83,20 @@ static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
 // the groups hold >= 64 samples.
 static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta_fold = false)
 {
+    if (!delta_fold && c->af_table_ok && c->tune.af_tables && a_ub >= 64) {
+        // full pass as table lookups (k_score_aft): 2,048-variant tiles, 512 threads = 32 samples per round; groups of
+        // >= 128 samples so that a workgroup's table build (once per tile and group) stays in the percents
+        const u64 tiles = ch.wp / UTM_AFT_TILE_WORDS;
+        unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 127) / 128, ((u64)c->tune.af_target_wgs + tiles - 1) / std::max<u64>(1, tiles)));
+        n_groups = std::max(n_groups, (a_ub + UTM_AFT_MAX_GROUP - 1) / UTM_AFT_MAX_GROUP);  // (the group's sample list sits in LDS)
+        const unsigned group = ((a_ub + n_groups - 1) / n_groups + 31) / 32 * 32;
+        n_groups = (a_ub + group - 1) / group;
+        LaunchTimer t(c);
+        hipExtLaunchKernelGGL(k_score_aft, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(UTM_AFT_THREADS), 0, c->stream, t.start, t.stop, 0,
+                              ch.cols, ch.covered, ch.wp, ch.afx, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, group, n_groups);
+        c->af_table_passes += 1;
+        return;
+    }
     const int af_target = c->tune.af_target_wgs;
     const u64 tiles = ch.wp / UTM_AF_TILE_WORDS;
     unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 63) / 64, (u64)af_target / std::max<u64>(1, tiles)));
@@ -892,6 +906,7 @@ extern "C" int utm_get_stats(utm_ctx *c, utm_stats *out)
     out->persist_launches = c->persist_launches;
     out->persist_iterations = c->persist_iterations;
     out->persist_unresolved = c->persist_unresolved;
+    out->af_table_passes = c->af_table_passes;
     out->rccl_ranks = 0;
     if (c->comm) {
         int n = 0;

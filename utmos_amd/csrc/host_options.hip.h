@@ -96,6 +96,7 @@ static int build_af_tables(utm_ctx *c)
     (void)hipFree(c->d_seq_alt);
     c->d_seq = c->d_seq_alt = nullptr;
     c->af_fixed = false;
+    c->af_table_ok = false;
     c->af_q = 0;
     if (c->af_mode == UTM_AF_NONE) { c->dirty_tables = false; return UTM_OK; }
     for (auto &ch : c->chunks)
@@ -155,6 +156,7 @@ static int build_af_tables(utm_ctx *c)
             // the estimate's table: floor(a * 2^q) as mantissa << shift (af_fixed(), score_af.hip.h)
             std::vector<unsigned> fx(n, 0u);
             const int e_base = 150 - c->af_q;
+            if (k == 0) c->af_table_ok = true;
             for (u64 v = 0; v < ch.n_var; ++v) {
                 unsigned bits;
                 memcpy(&bits, &v32[k][v], 4);
@@ -162,6 +164,7 @@ static int build_af_tables(utm_ctx *c)
                 const unsigned m = (bits & 0x7FFFFFu) | 0x800000u;
                 const int sh = (int)(bits >> 23) - e_base;
                 fx[v] = sh >= 0 ? ((unsigned)sh << 24) | m : (sh > -24 ? m >> -sh : 0u);
+                if (sh > 22) c->af_table_ok = false;  // (k_score_aft's limbs: every value below 2^46)
             }
             HIP_TRY(hipMalloc(&ch.afx, n * 4));
             HIP_TRY(copy_sync(c, ch.afx, fx.data(), n * 4, hipMemcpyHostToDevice));

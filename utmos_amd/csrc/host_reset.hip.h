@@ -196,6 +196,7 @@ extern "C" int utm_reset(utm_ctx *c)
     c->finished = false;
     c->score_launches = 0;
     c->persist_launches = c->persist_iterations = c->persist_unresolved = 0;
+    c->af_table_passes = 0;
     c->loop_unresolved = false;
     c->persist_backoff = c->persist_backoff_len = 0;
     c->score_ms = 0;

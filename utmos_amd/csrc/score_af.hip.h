@@ -125,6 +125,151 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1-AF, full dense pass as table lookups (the first iteration of an --af run: nothing is covered yet, so every set bit
+// of the matrix counts and walking them one by one is VALU work proportional to the density, a wave running as long
+// as its fullest lane).  Here the work per column byte is fixed: the tile's variants are cut into groups of 4, every
+// group gets a 16-entry table of the exact partial sums of its live members (a covered variant, or one with AF == 0,
+// adds nothing), and a column nibble IS the index into its group's table -- one ds_read_b64 and one add per 4 variants,
+// no bit loop, no divergence.
+//   Tile = 2,048 variants = 256 B of every column = 16 lanes x 16 B: a wave instruction reads four samples' pieces,
+// lane `sub` of a quarter wave owns the same 128 variants for every sample, i.e. the same 32 groups.  Table layout
+// (64 KiB, two workgroups per CU): entry (group j of lane sub, nibble b) sits at
+//     j even:  32768 + (j/2) * 2048 + b * 128  + sub * 8        j odd:  (j/2) * 128 + b * 2048 + sub * 8
+// so that ONE shifted copy of a column dword yields two addresses with an AND-OR each (the even nibble lands on bits
+// 7..10, the odd one on bits 11..14, sub * 8 below them, the rest is the instruction's immediate offset), and a
+// ds_read_b64's 32-lane group (two samples x 16 subs) conflicts at most 2-way (same sub, different nibble).
+//   An entry is kept as two 32-bit limbs (value = hi * 2^26 + lo, lo < 2^26): a lane adds its 32 entries with v_add3_u32
+// and no carries; the host admits the kernel only when every table value is below 2^46 (af_table_ok), so that a
+// lane's 128 variants stay below 2^53 and neither limb sum (nor, after one normalisation, their 16-lane DPP row sums)
+// can overflow.  Same integer sums as k_score_afq, same atomics.
+// ------------------------------------------------------------------------------------------------
+#define UTM_AFT_TILE_WORDS 32
+#define UTM_AFT_THREADS 512
+#define UTM_AFT_LIMB 26
+#define UTM_AFT_MAX_GROUP 1024
+__device__ __forceinline__ u64 aft_limbs(u64 v)
+{
+    return (v & ((1ull << UTM_AFT_LIMB) - 1)) | ((v >> UTM_AFT_LIMB) << 32);
+}
+__device__ __forceinline__ unsigned row_sum16(unsigned v)  // DPP row shifts: lane 15 of every 16-lane row ends up with its row's sum
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    return v;
+}
+__global__ __launch_bounds__(UTM_AFT_THREADS) void k_score_aft(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
+                                                               const unsigned *__restrict__ af, const Pending pend,
+                                                               const IterState *__restrict__ st, const unsigned *__restrict__ act,
+                                                               u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
+                                                               unsigned n_groups)
+{
+    __shared__ __attribute__((aligned(16))) u64 tab[8192];  // 64 KiB, layout above
+    __shared__ u64 live[UTM_AFT_TILE_WORDS];
+    __shared__ unsigned sact[UTM_AFT_MAX_GROUP];  // the group's samples (a column request must not wait for a global act[] read)
+    if (st->done) return;
+    unsigned tile, grp;
+    if (!tile_of_block(wp, UTM_AFT_TILE_WORDS, n_groups, tile, grp)) return;
+    const u64 w0 = (u64)tile * UTM_AFT_TILE_WORDS;
+    {
+        const unsigned n_act = st->n_active, a_lo = grp * group_size;
+        for (unsigned i = threadIdx.x; i < group_size && a_lo + i < n_act; i += UTM_AFT_THREADS) sact[i] = act[a_lo + i];
+    }
+    if (threadIdx.x < UTM_AFT_TILE_WORDS) {
+        const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
+        u64 c = covered[w0 + threadIdx.x];
+        if (wcol) {
+            c |= wcol[w0 + threadIdx.x];
+            if (grp == 0) covered[w0 + threadIdx.x] = c;
+        }
+        live[threadIdx.x] = ~c;
+    }
+    const unsigned n_active = st->n_active;
+    const unsigned lo = grp * group_size;
+    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const unsigned sub = lane & 15, quarter = lane >> 4;
+    constexpr int U = 2, NW = UTM_AFT_THREADS / 64;
+    // a unit = four samples' pieces of this tile (one wave instruction).  Two register sets of U units each: while one
+    // is walked the other is in flight, and a set is re-requested only after its last use (a slot refilled while its
+    // old contents are still live costs register copies behind a vmcnt(0) at the loop's end).  A request is
+    // unconditional -- beyond the group's end it re-reads the tile's covered words (L2 hits, ignored).
+    const unsigned n_units = (hi - lo + 3) / 4;
+    auto request = [&](unsigned unit, unsigned &s, v4u &x) {
+        const unsigned i = unit * 4 + quarter;  // position inside the group
+        const bool ok = lo + i < hi;
+        s = sact[ok ? i : 0];
+        const u64 *src = ok ? cols + (u64)s * wp + w0 : covered + w0;
+        x = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src) + sub);
+    };
+    unsigned sa[U], sb[U];
+    v4u xa[U], xb[U];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) request(wave + u * NW, sa[u], xa[u]);  // (on their way while the tables are built)
+    {   // the tables: thread (j, sub) builds the 16 partial sums of variants sub * 128 + j * 4 .. + 3
+        const unsigned bj = threadIdx.x >> 4, bsub = threadIdx.x & 15;
+        const v4u e = reinterpret_cast<const v4u *>(af + w0 * 64)[bsub * 32 + bj];
+        const unsigned lv = (unsigned)(live[bsub * 2 + (bj >> 4)] >> ((bj & 15) * 4)) & 15u;
+        const u64 q0 = (lv & 1) ? af_fixed(e.x) : 0ull, q1 = (lv & 2) ? af_fixed(e.y) : 0ull;
+        const u64 q2 = (lv & 4) ? af_fixed(e.z) : 0ull, q3 = (lv & 8) ? af_fixed(e.w) : 0ull;
+        u64 t[16];
+        t[0] = 0; t[1] = q0; t[2] = q1; t[3] = q0 + q1;
+        t[4] = q2; t[5] = q2 + q0; t[6] = q2 + q1; t[7] = q2 + t[3];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) t[8 + b] = q3 + t[b];
+        char *base = reinterpret_cast<char *>(tab) + ((bj & 1) ? (bj >> 1) * 128 : 32768 + (bj >> 1) * 2048) + bsub * 8;
+        const unsigned stride = (bj & 1) ? 2048 : 128;
+#pragma unroll
+        for (int b = 0; b < 16; ++b) *reinterpret_cast<u64 *>(base + b * stride) = aft_limbs(t[b]);
+    }
+    const v4u m = reinterpret_cast<const v4u *>(live)[sub];  // this lane's 128 live bits, for the counts
+    __syncthreads();
+    const char *tb = reinterpret_cast<const char *>(tab);
+    const unsigned sub8 = sub * 8;
+    auto walk = [&](unsigned unit, unsigned s, const v4u &x) {
+            if (unit >= n_units) return;  // wave uniform
+            const unsigned iu = lo + unit * 4;
+            const bool valid = iu + quarter < hi;
+            const unsigned n_lane = valid ? __popc(x.x & m.x) + __popc(x.y & m.y) + __popc(x.z & m.z) + __popc(x.w & m.w) : 0u;
+            if (__ballot(n_lane != 0) == 0) return;  // wave uniform
+            unsigned alo = 0, ahi = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned y = k == 0 ? x[d] << 7 : x[d] >> (8 * k - 7);
+                    const int p = 4 * d + k;
+                    const u64 ev = *reinterpret_cast<const u64 *>(tb + ((y & 0x780u) | sub8) + (32768 + p * 2048));
+                    const u64 od = *reinterpret_cast<const u64 *>(tb + ((y & 0x7800u) | sub8) + p * 128);
+                    alo += (unsigned)ev + (unsigned)od;
+                    ahi += (unsigned)(ev >> 32) + (unsigned)(od >> 32);
+                }
+            }
+            ahi += alo >> UTM_AFT_LIMB;  // lane: lo < 2^26, hi < 2^27 -- the row sums below stay inside 32 bits
+            alo &= (1u << UTM_AFT_LIMB) - 1;
+            if (!valid) alo = ahi = 0;  // (a tail quarter re-read a real sample)
+            const unsigned n = row_sum16(n_lane);
+            const unsigned tlo = row_sum16(alo), thi = row_sum16(ahi);
+            if (sub == 15 && n) {
+                atomicAdd(&cnt[s], (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), ((u64)thi << UTM_AFT_LIMB) + tlo);
+            }
+    };
+    for (unsigned k = wave; k < n_units; k += 2 * U * NW) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) request(k + (U + u) * NW, sb[u], xb[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) walk(k + u * NW, sa[u], xa[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) request(k + (2 * U + u) * NW, sa[u], xa[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) walk(k + (U + u) * NW, sb[u], xb[u]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1-AF, sparse phase: once a good part of the variants is covered most loaded words are zero after
 // the AND, so this kernel is k_score_int's streaming loop (LDS-staged ~covered tile, 8 KiB in flight
 // per wave) plus a per-wave LDS queue: surviving bits only *enqueue* their variant index (prefix sum

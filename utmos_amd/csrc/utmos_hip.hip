@@ -122,7 +122,7 @@ static int rccl_load()
 struct Tune {
     int target_wgs, min_wgs, min_wgs_big, tile_steps, nt_loads, nt_min_mb;  // scoring grid shape
     int fuse_pick, pick_threads, batch;                                      // pick placement, host sync distance
-    int af_steps, af_target_wgs, chain_pick, af_verify, af_record, af_defer; // AF kernels
+    int af_steps, af_target_wgs, af_tables, chain_pick, af_verify, af_record, af_defer; // AF kernels
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
@@ -149,6 +149,7 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_BATCH", batch, 0),
     UTM_KNOB_I("UTM_AF_STEPS", af_steps, 16),
     UTM_KNOB_I("UTM_AF_TARGET_WGS", af_target_wgs, 16384),
+    UTM_KNOB_I("UTM_AF_TABLES", af_tables, 1),  // full dense AF passes as table lookups (k_score_aft) where the table admits it; 0: k_score_afq
     UTM_KNOB_I("UTM_CHAIN_PICK", chain_pick, 1),
     UTM_KNOB_I("UTM_AF_VERIFY", af_verify, 1),
     UTM_KNOB_I("UTM_AF_RECORD", af_record, 1),
@@ -254,6 +255,7 @@ struct utm_ctx {
     size_t claim_bytes = 0;
     bool persist_off = false;          // ... a census failed on this context (not every block resident): launch per iteration from now on
     i64 persist_launches = 0, persist_iterations = 0;  // statistics since the last utm_reset
+    i64 af_table_passes = 0;           // full dense AF passes taken by k_score_aft
     i64 persist_unresolved = 0;        // ... launches of the interval form that left their last iteration to the verification launch
     bool loop_unresolved = false;      // ... and that iteration is still to be decided (utm_run)
     i64 persist_backoff = 0, persist_backoff_len = 0;  // ... iterations to run as launches before the interval form is tried again
@@ -312,6 +314,7 @@ struct utm_ctx {
     int af_mode = UTM_AF_NONE;
     bool af_fixed = false;  // AF runs as the verified-parallel scheme (exact fixed-point estimate + chains)
     bool af_trunc = false;  // ... with a unit coarser than the smallest AF's last mantissa bit (addends lose < 1 unit each)
+    bool af_table_ok = false;  // every fixed-point value is below 2^46: the full pass may take the table kernel (k_score_aft)
     int af_q = 0;
     bool prepared = false;  // device loop state matches h_state / AF tables
     bool dirty_tables = true;
