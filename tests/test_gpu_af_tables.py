@@ -25,7 +25,7 @@ def _af_of(dense, n_samp, kind):
 
 
 @pytest.mark.parametrize("tables", ["1", "0"])
-@pytest.mark.parametrize("n_samp", [64, 65, 131, 300])
+@pytest.mark.parametrize("n_samp", [65, 66, 67, 131, 300])
 def test_select_all_checks_every_samples_first_pass_sum(dev, tables, n_samp, monkeypatch):
     """float32 AF in the exact range: a winner's reported score IS its accumulator (first full pass minus the delta
     passes' exact decreases), so a select-all run compares every sample's first-pass sum with the oracle, bit for bit."""
@@ -40,7 +40,8 @@ def test_select_all_checks_every_samples_first_pass_sum(dev, tables, n_samp, mon
     state[n_samp - 1] = 0                       # already used: its variants start out covered
     got, st = check_run(dev, dense, state=state, af=af)
     assert len(got[0]) > n_samp // 2
-    assert st["af_table_passes"] == (1 if tables == "1" else 0), st
+    # (two samples are not selectable: below 64 selectable ones the pass stays with k_score_afq)
+    assert st["af_table_passes"] == (1 if tables == "1" and n_samp - 2 >= 64 else 0), st
 
 
 @pytest.mark.parametrize("tables", ["1", "0"])

@@ -20,7 +20,7 @@ for r in csv.DictReader(open(f)):
     n = r["Name"].replace("void ", "")
     if n.startswith("k_score_af"):
         avg = float(r["AverageNs"]) / 1e3
-        print(f"UTM_AF_TABLES={t} {n[:34]:34s} calls={r['Calls']:>4s} avg_us={avg:9.2f} min_us={float(r['MinNs'])/1e3:9.2f} max_us={float(r['MaxNs'])/1e3:9.2f}  matrix {gb:.3f} GB -> {gb/avg*1e3:7.1f} GB/s at avg = {gb/avg*1e3/8000:.3f} of 8 TB/s")
+        print(f"UTM_AF_TABLES={t} {n[:34]:34s} calls={r['Calls']:>4s} avg_us={avg:9.2f} min_us={float(r['MinNs'])/1e3:9.2f} max_us={float(r['MaxNs'])/1e3:9.2f}  matrix {gb:.3f} GB -> {gb/avg*1e6:7.1f} GB/s at avg = {gb/avg*1e6/8000:.3f} of 8 TB/s")
 PY
   find $d -name "*.csv" -size +3M -delete
 done

@@ -84,7 +84,7 @@ static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
 static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta_fold = false)
 {
     if (!delta_fold && c->af_table_ok && c->tune.af_tables && a_ub >= 64) {
-        // full pass as table lookups (k_score_aft): 2,048-variant tiles, 512 threads = 32 samples per round; groups of
+        // full pass as table lookups (k_score_aft): 4,096-variant tiles, 1,024 threads = 32 samples per round; groups of
         // >= 128 samples so that a workgroup's table build (once per tile and group) stays in the percents
         const u64 tiles = ch.wp / UTM_AFT_TILE_WORDS;
         unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 127) / 128, ((u64)c->tune.af_target_wgs + tiles - 1) / std::max<u64>(1, tiles)));

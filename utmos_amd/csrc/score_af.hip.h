@@ -131,50 +131,63 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 // group gets a 16-entry table of the exact partial sums of its live members (a covered variant, or one with AF == 0,
 // adds nothing), and a column nibble IS the index into its group's table -- one ds_read_b64 and one add per 4 variants,
 // no bit loop, no divergence.
-//   Tile = 2,048 variants = 256 B of every column = 16 lanes x 16 B: a wave instruction reads four samples' pieces,
-// lane `sub` of a quarter wave owns the same 128 variants for every sample, i.e. the same 32 groups.  Table layout
-// (64 KiB, two workgroups per CU): entry (group j of lane sub, nibble b) sits at
-//     j even:  32768 + (j/2) * 2048 + b * 128  + sub * 8        j odd:  (j/2) * 128 + b * 2048 + sub * 8
+//   Tile = 4,096 variants = 512 B of every column = 32 lanes x 16 B: a wave instruction reads two samples' pieces,
+// lane `sub` of a half wave owns the same 128 variants for every sample, i.e. the same 32 groups.  Table layout
+// (128 KiB, one 1,024-thread workgroup per CU): entry (group j of lane sub, nibble b) sits at
+//     j even:  65536 + (j/2) * 4096 + b * 256  + sub * 8        j odd:  (j/2) * 256 + b * 4096 + sub * 8
 // so that ONE shifted copy of a column dword yields two addresses with an AND-OR each (the even nibble lands on bits
-// 7..10, the odd one on bits 11..14, sub * 8 below them, the rest is the instruction's immediate offset), and a
-// ds_read_b64's 32-lane group (two samples x 16 subs) conflicts at most 2-way (same sub, different nibble).
+// 8..11, the odd one on bits 12..15, sub * 8 below them, the rest is the instruction's immediate offset), and the 32
+// lanes a ds_read_b64 serves per LDS cycle (one sample's 32 subs) always fall on 32 different bank pairs, whatever
+// their nibbles are: no bank conflicts (the first form, two samples per 32 lanes on one table copy, spent as many LDS
+// cycles on conflicts as on reads).
 //   An entry is kept as two 32-bit limbs (value = hi * 2^26 + lo, lo < 2^26): a lane adds its 32 entries with v_add3_u32
 // and no carries; the host admits the kernel only when every table value is below 2^46 (af_table_ok), so that a
-// lane's 128 variants stay below 2^53 and neither limb sum (nor, after one normalisation, their 16-lane DPP row sums)
+// lane's 128 variants stay below 2^53 and neither limb sum (nor, after one normalisation, their 32-lane DPP sums)
 // can overflow.  Same integer sums as k_score_afq, same atomics.
 // ------------------------------------------------------------------------------------------------
-#define UTM_AFT_TILE_WORDS 32
-#define UTM_AFT_THREADS 512
+#define UTM_AFT_TILE_WORDS 64
+#define UTM_AFT_THREADS 1024
 #define UTM_AFT_LIMB 26
 #define UTM_AFT_MAX_GROUP 1024
 __device__ __forceinline__ u64 aft_limbs(u64 v)
 {
     return (v & ((1ull << UTM_AFT_LIMB) - 1)) | ((v >> UTM_AFT_LIMB) << 32);
 }
-__device__ __forceinline__ unsigned row_sum16(unsigned v)  // DPP row shifts: lane 15 of every 16-lane row ends up with its row's sum
+__device__ __forceinline__ unsigned half_sum32(unsigned v)  // DPP: lanes 31 and 63 end up with their half wave's sum
 {
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
     return v;
 }
+struct AftSample {
+    unsigned s;    // local sample
+    unsigned kib;  // its column's offset inside the chunk, in KiB (columns are whole KiB: s * wp / 128)
+};
 __global__ __launch_bounds__(UTM_AFT_THREADS) void k_score_aft(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
                                                                const unsigned *__restrict__ af, const Pending pend,
                                                                const IterState *__restrict__ st, const unsigned *__restrict__ act,
                                                                u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
                                                                unsigned n_groups)
 {
-    __shared__ __attribute__((aligned(16))) u64 tab[8192];  // 64 KiB, layout above
-    __shared__ u64 live[UTM_AFT_TILE_WORDS];
-    __shared__ unsigned sact[UTM_AFT_MAX_GROUP];  // the group's samples (a column request must not wait for a global act[] read)
+    __shared__ __attribute__((aligned(16))) u64 tab[16384];  // 128 KiB, layout above
+    __shared__ __attribute__((aligned(16))) u64 live[UTM_AFT_TILE_WORDS];
+    __shared__ AftSample sact[UTM_AFT_MAX_GROUP];  // the group's samples (a column request must not wait for a global act[] read)
     if (st->done) return;
     unsigned tile, grp;
     if (!tile_of_block(wp, UTM_AFT_TILE_WORDS, n_groups, tile, grp)) return;
     const u64 w0 = (u64)tile * UTM_AFT_TILE_WORDS;
+    const unsigned n_active = st->n_active;
+    const unsigned lo = grp * group_size;
+    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
     {
-        const unsigned n_act = st->n_active, a_lo = grp * group_size;
-        for (unsigned i = threadIdx.x; i < group_size && a_lo + i < n_act; i += UTM_AFT_THREADS) sact[i] = act[a_lo + i];
+        const unsigned kib_per_col = (unsigned)(wp / 128);
+        for (unsigned i = threadIdx.x; lo + i < hi; i += UTM_AFT_THREADS) {
+            const unsigned s = act[lo + i];
+            sact[i] = AftSample{s, s * kib_per_col};
+        }
     }
     if (threadIdx.x < UTM_AFT_TILE_WORDS) {
         const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
@@ -185,23 +198,23 @@ __global__ __launch_bounds__(UTM_AFT_THREADS) void k_score_aft(const u64 *__rest
         }
         live[threadIdx.x] = ~c;
     }
-    const unsigned n_active = st->n_active;
-    const unsigned lo = grp * group_size;
-    const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const unsigned sub = lane & 15, quarter = lane >> 4;
+    const unsigned sub = lane & 31, half = lane >> 5;
     constexpr int U = 2, NW = UTM_AFT_THREADS / 64;
-    // a unit = four samples' pieces of this tile (one wave instruction).  Two register sets of U units each: while one
+    // a unit = two samples' pieces of this tile (one wave instruction).  Two register sets of U units each: while one
     // is walked the other is in flight, and a set is re-requested only after its last use (a slot refilled while its
     // old contents are still live costs register copies behind a vmcnt(0) at the loop's end).  A request is
     // unconditional -- beyond the group's end it re-reads the tile's covered words (L2 hits, ignored).
-    const unsigned n_units = (hi - lo + 3) / 4;
+    const unsigned n_units = (hi - lo + 1) / 2;
+    const char *col_lane = reinterpret_cast<const char *>(cols + w0) + sub * 16;
+    const char *dummy_lane = reinterpret_cast<const char *>(covered + w0) + sub * 16;
     auto request = [&](unsigned unit, unsigned &s, v4u &x) {
-        const unsigned i = unit * 4 + quarter;  // position inside the group
+        const unsigned i = unit * 2 + half;  // position inside the group
         const bool ok = lo + i < hi;
-        s = sact[ok ? i : 0];
-        const u64 *src = ok ? cols + (u64)s * wp + w0 : covered + w0;
-        x = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src) + sub);
+        const AftSample a = sact[ok ? i : 0];
+        s = a.s;
+        const char *src = ok ? col_lane + ((u64)a.kib << 10) : dummy_lane;
+        x = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src));
     };
     unsigned sa[U], sb[U];
     v4u xa[U], xb[U];
@@ -209,7 +222,7 @@ __global__ __launch_bounds__(UTM_AFT_THREADS) void k_score_aft(const u64 *__rest
 #pragma unroll
     for (int u = 0; u < U; ++u) request(wave + u * NW, sa[u], xa[u]);  // (on their way while the tables are built)
     {   // the tables: thread (j, sub) builds the 16 partial sums of variants sub * 128 + j * 4 .. + 3
-        const unsigned bj = threadIdx.x >> 4, bsub = threadIdx.x & 15;
+        const unsigned bj = threadIdx.x >> 5, bsub = threadIdx.x & 31;
         const v4u e = reinterpret_cast<const v4u *>(af + w0 * 64)[bsub * 32 + bj];
         const unsigned lv = (unsigned)(live[bsub * 2 + (bj >> 4)] >> ((bj & 15) * 4)) & 15u;
         const u64 q0 = (lv & 1) ? af_fixed(e.x) : 0ull, q1 = (lv & 2) ? af_fixed(e.y) : 0ull;
@@ -219,43 +232,43 @@ __global__ __launch_bounds__(UTM_AFT_THREADS) void k_score_aft(const u64 *__rest
         t[4] = q2; t[5] = q2 + q0; t[6] = q2 + q1; t[7] = q2 + t[3];
 #pragma unroll
         for (int b = 0; b < 8; ++b) t[8 + b] = q3 + t[b];
-        char *base = reinterpret_cast<char *>(tab) + ((bj & 1) ? (bj >> 1) * 128 : 32768 + (bj >> 1) * 2048) + bsub * 8;
-        const unsigned stride = (bj & 1) ? 2048 : 128;
+        char *base = reinterpret_cast<char *>(tab) + ((bj & 1) ? (bj >> 1) * 256 : 65536 + (bj >> 1) * 4096) + bsub * 8;
+        const unsigned stride = (bj & 1) ? 4096 : 256;
 #pragma unroll
         for (int b = 0; b < 16; ++b) *reinterpret_cast<u64 *>(base + b * stride) = aft_limbs(t[b]);
     }
     const v4u m = reinterpret_cast<const v4u *>(live)[sub];  // this lane's 128 live bits, for the counts
     __syncthreads();
     const char *tb = reinterpret_cast<const char *>(tab);
-    const unsigned sub8 = sub * 8;
+    unsigned sub_odd = sub * 8, sub_even = 65536u | (sub * 8);
+    asm volatile("" : "+v"(sub_odd), "+v"(sub_even));  // (opaque: an OR the compiler can see through becomes v_and + v_add instead of one v_and_or)
     auto walk = [&](unsigned unit, unsigned s, const v4u &x) {
-            if (unit >= n_units) return;  // wave uniform
-            const unsigned iu = lo + unit * 4;
-            const bool valid = iu + quarter < hi;
-            const unsigned n_lane = valid ? __popc(x.x & m.x) + __popc(x.y & m.y) + __popc(x.z & m.z) + __popc(x.w & m.w) : 0u;
-            if (__ballot(n_lane != 0) == 0) return;  // wave uniform
-            unsigned alo = 0, ahi = 0;
+        if (unit >= n_units) return;  // wave uniform
+        const bool valid = lo + unit * 2 + half < hi;
+        const unsigned n_lane = valid ? __popc(x.x & m.x) + __popc(x.y & m.y) + __popc(x.z & m.z) + __popc(x.w & m.w) : 0u;
+        if (__ballot(n_lane != 0) == 0) return;  // wave uniform
+        unsigned alo = 0, ahi = 0;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
+        for (int d = 0; d < 4; ++d) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const unsigned y = k == 0 ? x[d] << 7 : x[d] >> (8 * k - 7);
-                    const int p = 4 * d + k;
-                    const u64 ev = *reinterpret_cast<const u64 *>(tb + ((y & 0x780u) | sub8) + (32768 + p * 2048));
-                    const u64 od = *reinterpret_cast<const u64 *>(tb + ((y & 0x7800u) | sub8) + p * 128);
-                    alo += (unsigned)ev + (unsigned)od;
-                    ahi += (unsigned)(ev >> 32) + (unsigned)(od >> 32);
-                }
+            for (int k = 0; k < 4; ++k) {
+                const unsigned y = k == 0 ? x[d] << 8 : x[d] >> (8 * k - 8);
+                const int p = 4 * d + k;
+                const u64 ev = *reinterpret_cast<const u64 *>(tb + ((y & 0xF00u) | sub_even) + p * 4096);
+                const u64 od = *reinterpret_cast<const u64 *>(tb + ((y & 0xF000u) | sub_odd) + p * 256);
+                alo += (unsigned)ev + (unsigned)od;
+                ahi += (unsigned)(ev >> 32) + (unsigned)(od >> 32);
             }
-            ahi += alo >> UTM_AFT_LIMB;  // lane: lo < 2^26, hi < 2^27 -- the row sums below stay inside 32 bits
-            alo &= (1u << UTM_AFT_LIMB) - 1;
-            if (!valid) alo = ahi = 0;  // (a tail quarter re-read a real sample)
-            const unsigned n = row_sum16(n_lane);
-            const unsigned tlo = row_sum16(alo), thi = row_sum16(ahi);
-            if (sub == 15 && n) {
-                atomicAdd(&cnt[s], (u64)n);
-                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), ((u64)thi << UTM_AFT_LIMB) + tlo);
-            }
+        }
+        ahi += alo >> UTM_AFT_LIMB;  // lane: lo < 2^26, hi < 2^27 + 32 -- the 32-lane sums below stay inside 32 bits
+        alo &= (1u << UTM_AFT_LIMB) - 1;
+        if (!valid) alo = ahi = 0;  // (a tail half read something else)
+        const unsigned n = half_sum32(n_lane);
+        const unsigned tlo = half_sum32(alo), thi = half_sum32(ahi);
+        if (sub == 31 && n) {
+            atomicAdd(&cnt[s], (u64)n);
+            atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), ((u64)thi << UTM_AFT_LIMB) + tlo);
+        }
     };
     for (unsigned k = wave; k < n_units; k += 2 * U * NW) {
 #pragma unroll
