@@ -41,6 +41,8 @@
  *                             log of newly-covered masks (needs 64 columns + 8 bytes per variant of HBM; 0: chained on the spot)
  *   UTM_PICK_THREADS (auto)   threads of the stand-alone k_pick             UTM_BATCH (256; AF 64) iterations between host syncs
  *   UTM_AF_STEPS (16), UTM_AF_SWITCH (0.2), UTM_AF_TARGET_WGS (16384)       AF kernels: tile, dense->streaming switch, grid
+ *   UTM_AF_TABLES (1)         the full dense AF pass as table lookups (k_score_aft) where every fixed-point value is below 2^45; 0: k_score_afq
+ *   UTM_AF_TABLE_WGS_PER_CU (8), UTM_AF_TABLE_RUN (0 = by the grid)         ... its grid: workgroups per CU, or tiles per workgroup outright
  *   UTM_AF_DENSE_DELTA (0.05) AF delta passes take the LDS-tile kernel while the last winner newly covered more than this share of all variants
  *   UTM_DECR_FIRST_BATCH (8), UTM_DECR_INTERLEAVED (1)                      decremental mode: first batch size, second copy on/off
  *   UTM_P2P_REPLICATE (1)     copy the peers' columns once (0: read winners in place over the mappings)

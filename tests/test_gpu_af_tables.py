@@ -44,9 +44,14 @@ def test_select_all_checks_every_samples_first_pass_sum(dev, tables, n_samp, mon
     assert st["af_table_passes"] == (1 if tables == "1" and n_samp - 2 >= 64 else 0), st
 
 
-@pytest.mark.parametrize("tables", ["1", "0"])
+@pytest.mark.parametrize("tables", ["1", "0", "run3", "run40"])
 @pytest.mark.parametrize("kind", ["f32", "f64", "f32_chunks", "f32_weights"])
 def test_runs_with_the_table_pass(dev, tables, kind, monkeypatch):
+    """`run3` / `run8`: a workgroup keeps its samples' partial sums in registers over 3 / all tiles (6 tiles here: a short
+    last run, and one run shorter than asked for); by itself the host gives a matrix this small one tile per workgroup."""
+    if tables.startswith("run"):
+        monkeypatch.setenv("UTM_AF_TABLE_RUN", tables[3:])
+        tables = "1"
     monkeypatch.setenv("UTM_AF_TABLES", tables)
     rng = np.random.default_rng(77)
     n_var, n_samp = 2048 * 11 + 5, 150
@@ -59,8 +64,10 @@ def test_runs_with_the_table_pass(dev, tables, kind, monkeypatch):
     assert st["af_table_passes"] == (n_chunks if tables == "1" else 0), st
 
 
-def test_more_samples_than_one_group_holds(dev):
-    """Above 1,024 samples the sample axis is cut into groups (a group's list sits in LDS)."""
+@pytest.mark.parametrize("run", ["0", "2"])
+def test_more_samples_than_one_group_holds(dev, run, monkeypatch):
+    """Above 256 samples the sample axis is cut into groups (a wave keeps at most 8 units of two samples in registers)."""
+    monkeypatch.setenv("UTM_AF_TABLE_RUN", run)
     rng = np.random.default_rng(5)
     n_var, n_samp = 2048 * 2 + 64, 1100
     dense = rng.random((n_var, n_samp)) < 0.02
@@ -71,7 +78,7 @@ def test_more_samples_than_one_group_holds(dev):
 
 
 def test_values_too_wide_for_the_limbs_keep_the_bit_walking_kernel(dev):
-    """Exponents spread over more than 22 bits: a table value could pass 2^46 units, k_score_aft is not admitted."""
+    """Exponents spread over more than 21 bits: a table value could pass 2^45 units, k_score_aft is not admitted."""
     rng = np.random.default_rng(6)
     n_var, n_samp = 9000, 80
     dense = ou.random_dense(rng, n_var, n_samp)
@@ -80,10 +87,12 @@ def test_values_too_wide_for_the_limbs_keep_the_bit_walking_kernel(dev):
     assert st["af_table_passes"] == 0, st
 
 
-def test_dense_columns(dev):
-    """Every nibble value occurs: half of all cells set."""
+@pytest.mark.parametrize("n_samp", [96, 130, 200, 257])
+def test_dense_columns(dev, n_samp, monkeypatch):
+    """Every nibble value occurs: half of all cells set.  130 samples: groups of 4 units per wave instead of 8."""
+    monkeypatch.setenv("UTM_AF_TABLE_RUN", "4")
     rng = np.random.default_rng(8)
-    n_var, n_samp = 2048 * 3, 96
+    n_var = 4096 * 5 + 100
     dense = rng.random((n_var, n_samp)) < 0.5
     af = _af_of(dense, n_samp, "f32")
     _, st = check_run(dev, dense, af=af, k=10)

@@ -81,19 +81,37 @@ static void launch_score_sequential(utm_ctx *c, unsigned a_ub)
 
 // AF, dense phase: LDS AF tiles.  Every workgroup re-stages its 32 KiB AF tile (from L2 / Infinity Cache), so
 // the groups hold >= 64 samples.
+// The full dense AF pass takes the table kernel (k_score_aft) when every fixed-point value fits its limbs.
+static bool af_table_pass(const utm_ctx *c, unsigned a_ub)
+{
+    return c->af_table_ok && c->tune.af_tables && a_ub >= 64;
+}
+
 static void launch_score_af_dense(utm_ctx *c, const Chunk &ch, unsigned a_ub, bool delta_fold = false)
 {
-    if (!delta_fold && c->af_table_ok && c->tune.af_tables && a_ub >= 64) {
-        // full pass as table lookups (k_score_aft): 4,096-variant tiles, 1,024 threads = 32 samples per round; groups of
-        // >= 128 samples so that a workgroup's table build (once per tile and group) stays in the percents
+    if (!delta_fold && af_table_pass(c, a_ub)) {
+        // full pass as table lookups (k_score_aft): 4,096-variant tiles, 1,024 threads; a workgroup = a run of up to
+        // UTM_AFT_RUN tiles x a group of at most 32 * MAXU samples (MAXU = 8 or 4 units of two samples per wave, kept in registers
+        // over the run).  The caller has applied the pending winner (enqueue_score).
         const u64 tiles = ch.wp / UTM_AFT_TILE_WORDS;
-        unsigned n_groups = (unsigned)std::max<u64>(1, std::min<u64>((a_ub + 127) / 128, ((u64)c->tune.af_target_wgs + tiles - 1) / std::max<u64>(1, tiles)));
-        n_groups = std::max(n_groups, (a_ub + UTM_AFT_MAX_GROUP - 1) / UTM_AFT_MAX_GROUP);  // (the group's sample list sits in LDS)
-        const unsigned group = ((a_ub + n_groups - 1) / n_groups + 31) / 32 * 32;
+        int maxu = 8;
+        unsigned n_groups = (a_ub + 32 * maxu - 1) / (32 * maxu);
+        if ((u64)(a_ub + 127) / 128 * 128 + 16 < (u64)n_groups * 256) { maxu = 4; n_groups = (a_ub + 127) / 128; }  // fewer idle units
+        const unsigned group = ((a_ub + n_groups - 1) / n_groups + 1) / 2 * 2;
         n_groups = (a_ub + group - 1) / group;
+        // runs: as long as possible while the grid still has about UTM_AF_TABLE_WGS_PER_CU workgroups per CU (one is
+        // resident per CU; the sums are flushed every UTM_AFT_RUN tiles inside the kernel)
+        const u64 want = 256ull * (u64)std::max(1, c->tune.af_table_wgs_per_cu);
+        unsigned run = (unsigned)std::max<u64>(1, (tiles * n_groups + want - 1) / want);  // (rounded up: the grid ends just below a multiple of the CUs)
+        if (c->tune.af_table_run >= 1) run = (unsigned)c->tune.af_table_run;
+        const unsigned n_runs = (unsigned)((tiles + run - 1) / run);
         LaunchTimer t(c);
-        hipExtLaunchKernelGGL(k_score_aft, dim3((unsigned)round_up(tiles * n_groups, 8)), dim3(UTM_AFT_THREADS), 0, c->stream, t.start, t.stop, 0,
-                              ch.cols, ch.covered, ch.wp, ch.afx, pending_of(c, ch, true), c->d_st, c->d_act, c->d_cnt, c->d_afsum, group, n_groups);
+#define UTM_LAUNCH_AFT(M)                                                                                                      \
+    hipExtLaunchKernelGGL(k_score_aft<M>, dim3((unsigned)round_up((u64)n_runs * n_groups, 8)), dim3(UTM_AFT_THREADS), 0, c->stream, t.start, \
+                          t.stop, 0, ch.cols, ch.covered, ch.wp, ch.afx, c->d_st, c->d_act, c->d_cnt, c->d_afsum, group, n_groups, run)
+        if (maxu == 8) UTM_LAUNCH_AFT(8);
+        else UTM_LAUNCH_AFT(4);
+#undef UTM_LAUNCH_AFT
         c->af_table_passes += 1;
         return;
     }
@@ -360,7 +378,7 @@ static int enqueue_score(utm_ctx *c, bool force_sequential = false, int fuse_pic
             HIP_TRY(hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream));
             const double af_switch = c->tune.af_switch;
             const bool af_dense = (double)c->captured_seen < af_switch * (double)c->n_var_total;
-            if (remote_reads(c)) launch_apply_pending(c);
+            if (remote_reads(c) || (af_dense && af_table_pass(c, a_ub))) launch_apply_pending(c);  // (k_score_aft reads `covered` as it is)
             for (auto &ch : c->chunks) {
                 if (af_dense) launch_score_af_dense(c, ch, a_ub);
                 else launch_score_streaming(c, ch, a_ub);

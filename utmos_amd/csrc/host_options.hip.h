@@ -164,7 +164,7 @@ static int build_af_tables(utm_ctx *c)
                 const unsigned m = (bits & 0x7FFFFFu) | 0x800000u;
                 const int sh = (int)(bits >> 23) - e_base;
                 fx[v] = sh >= 0 ? ((unsigned)sh << 24) | m : (sh > -24 ? m >> -sh : 0u);
-                if (sh > 22) c->af_table_ok = false;  // (k_score_aft's limbs: every value below 2^46)
+                if (sh > 21) c->af_table_ok = false;  // (k_score_aft's limbs: every value below 2^45)
             }
             HIP_TRY(hipMalloc(&ch.afx, n * 4));
             HIP_TRY(copy_sync(c, ch.afx, fx.data(), n * 4, hipMemcpyHostToDevice));

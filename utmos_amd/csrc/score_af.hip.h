@@ -131,27 +131,44 @@ __global__ __launch_bounds__(256) void k_score_afq(const u64 *__restrict__ cols,
 // group gets a 16-entry table of the exact partial sums of its live members (a covered variant, or one with AF == 0,
 // adds nothing), and a column nibble IS the index into its group's table -- one ds_read_b64 and one add per 4 variants,
 // no bit loop, no divergence.
-//   Tile = 4,096 variants = 512 B of every column = 32 lanes x 16 B: a wave instruction reads two samples' pieces,
-// lane `sub` of a half wave owns the same 128 variants for every sample, i.e. the same 32 groups.  Table layout
-// (128 KiB, one 1,024-thread workgroup per CU): entry (group j of lane sub, nibble b) sits at
+//   Tile = 4,096 variants = 512 B of every column = 32 lanes x 16 B: a wave instruction reads two samples' pieces (a
+// "unit"), lane `sub` of a half wave owns the same 128 variants for every sample, i.e. the same 32 groups.  Table
+// layout (128 KiB, one 1,024-thread workgroup per CU): entry (group j of lane sub, nibble b) sits at
 //     j even:  65536 + (j/2) * 4096 + b * 256  + sub * 8        j odd:  (j/2) * 256 + b * 4096 + sub * 8
 // so that ONE shifted copy of a column dword yields two addresses with an AND-OR each (the even nibble lands on bits
 // 8..11, the odd one on bits 12..15, sub * 8 below them, the rest is the instruction's immediate offset), and the 32
 // lanes a ds_read_b64 serves per LDS cycle (one sample's 32 subs) always fall on 32 different bank pairs, whatever
-// their nibbles are: no bank conflicts (the first form, two samples per 32 lanes on one table copy, spent as many LDS
-// cycles on conflicts as on reads).
-//   An entry is kept as two 32-bit limbs (value = hi * 2^26 + lo, lo < 2^26): a lane adds its 32 entries with v_add3_u32
-// and no carries; the host admits the kernel only when every table value is below 2^46 (af_table_ok), so that a
-// lane's 128 variants stay below 2^53 and neither limb sum (nor, after one normalisation, their 32-lane DPP sums)
-// can overflow.  Same integer sums as k_score_afq, same atomics.
+// their nibbles are: no bank conflicts.
+//   An entry is kept as two 32-bit limbs, the limb-wise sums of its members' limbs (a value = hi * 2^25 + lo, lo < 2^25;
+// an entry's lo limb is not carried into its hi limb, it stays below 2^27): a lane adds its 32 entries with v_add3_u32
+// and no carries (32 * (2^27 - 4) < 2^32) and carries once per unit and tile.  The host admits the kernel only when
+// every table value is below 2^45 (af_table_ok): a value's hi limb is then below 2^20, a lane's 128 variants add less
+// than 2^27 to its hi sum per tile, and 16 tiles stay inside 32 bits.
+//   A workgroup owns a group of samples and a run of consecutive tiles (as long as the grid allows: what a workgroup
+// pays before its first lookup -- act[] -> column requests -> table, two to three memory round trips under load --
+// and after its last measured 7 us, a tile 9): a wave keeps the SAME MAXU units for all of them, so a lane's partial
+// sums (lo, hi, count per unit) stay in registers across the tiles and the cross-lane reduction and the two atomics
+// per sample happen once per UTM_AFT_RUN tiles, not once per tile -- with them per tile the kernel spent a third of its
+// VALU work outside the lookups.  Per tile: barrier, every thread
+// builds one group's table from values it requested a tile earlier, barrier, the wave walks its units with D column
+// requests in flight.  Same integer sums as k_score_afq.  The pending winner is applied to `covered` beforehand (host).
 // ------------------------------------------------------------------------------------------------
 #define UTM_AFT_TILE_WORDS 64
 #define UTM_AFT_THREADS 1024
-#define UTM_AFT_LIMB 26
-#define UTM_AFT_MAX_GROUP 1024
-__device__ __forceinline__ u64 aft_limbs(u64 v)
+#define UTM_AFT_LIMB 25
+#define UTM_AFT_RUN 16    // tiles between two flushes of the per-lane sums: a lane's hi limb grows by < 2^27 + 2^7 per tile
+#define UTM_AFT_D 4       // column requests in flight per wave (1 KiB each); MAXU is a multiple
+struct AftLimbs {
+    unsigned lo, hi;
+};
+__device__ __forceinline__ AftLimbs aft_limbs(unsigned f, bool live)  // a table value (af_fixed) as limbs, 0 when its variant does not count
 {
-    return (v & ((1ull << UTM_AFT_LIMB) - 1)) | ((v >> UTM_AFT_LIMB) << 32);
+    const u64 v = live ? af_fixed(f) : 0ull;
+    return AftLimbs{(unsigned)v & ((1u << UTM_AFT_LIMB) - 1), (unsigned)(v >> UTM_AFT_LIMB)};
+}
+__device__ __forceinline__ AftLimbs operator+(const AftLimbs &a, const AftLimbs &b)
+{
+    return AftLimbs{a.lo + b.lo, a.hi + b.hi};
 }
 __device__ __forceinline__ unsigned half_sum32(unsigned v)  // DPP: lanes 31 and 63 end up with their half wave's sum
 {
@@ -162,123 +179,133 @@ __device__ __forceinline__ unsigned half_sum32(unsigned v)  // DPP: lanes 31 and
     v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
     return v;
 }
-struct AftSample {
-    unsigned s;    // local sample
-    unsigned kib;  // its column's offset inside the chunk, in KiB (columns are whole KiB: s * wp / 128)
-};
-__global__ __launch_bounds__(UTM_AFT_THREADS) void k_score_aft(const u64 *__restrict__ cols, u64 *__restrict__ covered, u64 wp,
-                                                               const unsigned *__restrict__ af, const Pending pend,
-                                                               const IterState *__restrict__ st, const unsigned *__restrict__ act,
-                                                               u64 *__restrict__ cnt, i64 *__restrict__ afsum, unsigned group_size,
-                                                               unsigned n_groups)
+// Grid: (runs of tiles) x (groups of samples), through tile_of_block with a run as its "tile".  group_size <= 32 * MAXU;
+// MAXU = 4 or 8 (12 units' accumulators and addresses no longer fit 128 registers).
+template <int MAXU>
+__global__ __launch_bounds__(UTM_AFT_THREADS) void k_score_aft(const u64 *__restrict__ cols, const u64 *__restrict__ covered, u64 wp,
+                                                               const unsigned *__restrict__ af, const IterState *__restrict__ st,
+                                                               const unsigned *__restrict__ act, u64 *__restrict__ cnt,
+                                                               i64 *__restrict__ afsum, unsigned group_size, unsigned n_groups,
+                                                               unsigned run_tiles)
 {
+    static_assert(MAXU % UTM_AFT_D == 0, "the request ring wraps at a tile's end");
     __shared__ __attribute__((aligned(16))) u64 tab[16384];  // 128 KiB, layout above
-    __shared__ __attribute__((aligned(16))) u64 live[UTM_AFT_TILE_WORDS];
-    __shared__ AftSample sact[UTM_AFT_MAX_GROUP];  // the group's samples (a column request must not wait for a global act[] read)
+    __shared__ unsigned s_of[UTM_AFT_THREADS / 64][MAXU][2];  // the samples behind a wave's units (for the flushes' atomics)
     if (st->done) return;
-    unsigned tile, grp;
-    if (!tile_of_block(wp, UTM_AFT_TILE_WORDS, n_groups, tile, grp)) return;
-    const u64 w0 = (u64)tile * UTM_AFT_TILE_WORDS;
+    unsigned run, grp;
+    if (!tile_of_block(wp, UTM_AFT_TILE_WORDS * run_tiles, n_groups, run, grp)) return;
+    const u64 w_first = (u64)run * run_tiles * UTM_AFT_TILE_WORDS;
+    const unsigned n_t = (unsigned)((wp - w_first) / UTM_AFT_TILE_WORDS < run_tiles ? (wp - w_first) / UTM_AFT_TILE_WORDS : run_tiles);
     const unsigned n_active = st->n_active;
     const unsigned lo = grp * group_size;
     const unsigned hi = lo + group_size < n_active ? lo + group_size : n_active;
-    {
-        const unsigned kib_per_col = (unsigned)(wp / 128);
-        for (unsigned i = threadIdx.x; lo + i < hi; i += UTM_AFT_THREADS) {
-            const unsigned s = act[lo + i];
-            sact[i] = AftSample{s, s * kib_per_col};
-        }
-    }
-    if (threadIdx.x < UTM_AFT_TILE_WORDS) {
-        const u64 *wcol = pend.fuse ? pending_column(st, cols, wp, pend) : nullptr;
-        u64 c = covered[w0 + threadIdx.x];
-        if (wcol) {
-            c |= wcol[w0 + threadIdx.x];
-            if (grp == 0) covered[w0 + threadIdx.x] = c;
-        }
-        live[threadIdx.x] = ~c;
-    }
+    if (lo >= hi) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned sub = lane & 31, half = lane >> 5;
-    constexpr int U = 2, NW = UTM_AFT_THREADS / 64;
-    // a unit = two samples' pieces of this tile (one wave instruction).  Two register sets of U units each: while one
-    // is walked the other is in flight, and a set is re-requested only after its last use (a slot refilled while its
-    // old contents are still live costs register copies behind a vmcnt(0) at the loop's end).  A request is
-    // unconditional -- beyond the group's end it re-reads the tile's covered words (L2 hits, ignored).
+    constexpr int NW = UTM_AFT_THREADS / 64, D = UTM_AFT_D;
+    // this wave's units: unit u = positions lo + 2 * (wave + NW * u) + {0, 1} of act[]; a lane without a sample of
+    // its own (the group's ragged end) reads the group's last sample instead and is cleared at the end
     const unsigned n_units = (hi - lo + 1) / 2;
-    const char *col_lane = reinterpret_cast<const char *>(cols + w0) + sub * 16;
-    const char *dummy_lane = reinterpret_cast<const char *>(covered + w0) + sub * 16;
-    auto request = [&](unsigned unit, unsigned &s, v4u &x) {
-        const unsigned i = unit * 2 + half;  // position inside the group
-        const bool ok = lo + i < hi;
-        const AftSample a = sact[ok ? i : 0];
-        s = a.s;
-        const char *src = ok ? col_lane + ((u64)a.kib << 10) : dummy_lane;
-        x = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(src));
-    };
-    unsigned sa[U], sb[U];
-    v4u xa[U], xb[U];
-    __syncthreads();
+    const unsigned n_my = (unsigned)wave < n_units ? (n_units - wave + NW - 1) / NW : 0;  // wave uniform
+    // what the next tile's build needs, requested a tile ahead (the first tile's before the column
+    // requests, which must wait for act[]: the first build then runs while those are in flight): this thread's group (j, sub) = 4 table values and the
+    // covered word they fall into; and the lane's own 128 covered bits for the counts
+    const unsigned bj = threadIdx.x >> 5, bsub = threadIdx.x & 31;
+    const unsigned *af_thread = af + w_first * 64 + (bsub * 32 + bj) * 4;
+    const u64 *cov_thread = covered + w_first + bsub * 2 + (bj >> 4);
+    const u64 *cov_lane = covered + w_first + sub * 2;
+    v4u e_next = *reinterpret_cast<const v4u *>(af_thread);
+    u64 c_next = *cov_thread;
+    v2q m_next = *reinterpret_cast<const v2q *>(cov_lane);
+    const char *pa[MAXU];  // where this lane's 16 B of unit u start in the current tile
 #pragma unroll
-    for (int u = 0; u < U; ++u) request(wave + u * NW, sa[u], xa[u]);  // (on their way while the tables are built)
-    {   // the tables: thread (j, sub) builds the 16 partial sums of variants sub * 128 + j * 4 .. + 3
-        const unsigned bj = threadIdx.x >> 5, bsub = threadIdx.x & 31;
-        const v4u e = reinterpret_cast<const v4u *>(af + w0 * 64)[bsub * 32 + bj];
-        const unsigned lv = (unsigned)(live[bsub * 2 + (bj >> 4)] >> ((bj & 15) * 4)) & 15u;
-        const u64 q0 = (lv & 1) ? af_fixed(e.x) : 0ull, q1 = (lv & 2) ? af_fixed(e.y) : 0ull;
-        const u64 q2 = (lv & 4) ? af_fixed(e.z) : 0ull, q3 = (lv & 8) ? af_fixed(e.w) : 0ull;
-        u64 t[16];
-        t[0] = 0; t[1] = q0; t[2] = q1; t[3] = q0 + q1;
-        t[4] = q2; t[5] = q2 + q0; t[6] = q2 + q1; t[7] = q2 + t[3];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) t[8 + b] = q3 + t[b];
-        char *base = reinterpret_cast<char *>(tab) + ((bj & 1) ? (bj >> 1) * 256 : 65536 + (bj >> 1) * 4096) + bsub * 8;
-        const unsigned stride = (bj & 1) ? 4096 : 256;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) *reinterpret_cast<u64 *>(base + b * stride) = aft_limbs(t[b]);
+    for (int u = 0; u < MAXU; ++u) {
+        const unsigned i = lo + 2 * (wave + NW * u) + half;
+        const unsigned s = act[i < hi ? i : hi - 1];
+        if (sub == 31) s_of[wave][u][half] = s;  // (read back by the same lane)
+        pa[u] = reinterpret_cast<const char *>(cols + (u64)s * wp + w_first) + sub * 16;
     }
-    const v4u m = reinterpret_cast<const v4u *>(live)[sub];  // this lane's 128 live bits, for the counts
-    __syncthreads();
+    v4u ring[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) ring[u] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(pa[u]));
+    unsigned alo[MAXU], ahi[MAXU], acn[MAXU];
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) alo[u] = ahi[u] = acn[u] = 0;
+    char *tb_w = reinterpret_cast<char *>(tab) + ((bj & 1) ? (bj >> 1) * 256 : 65536 + (bj >> 1) * 4096) + bsub * 8;
+    const unsigned w_stride = (bj & 1) ? 4096 : 256;
     const char *tb = reinterpret_cast<const char *>(tab);
     unsigned sub_odd = sub * 8, sub_even = 65536u | (sub * 8);
     asm volatile("" : "+v"(sub_odd), "+v"(sub_even));  // (opaque: an OR the compiler can see through becomes v_and + v_add instead of one v_and_or)
-    auto walk = [&](unsigned unit, unsigned s, const v4u &x) {
-        if (unit >= n_units) return;  // wave uniform
-        const bool valid = lo + unit * 2 + half < hi;
-        const unsigned n_lane = valid ? __popc(x.x & m.x) + __popc(x.y & m.y) + __popc(x.z & m.z) + __popc(x.w & m.w) : 0u;
-        if (__ballot(n_lane != 0) == 0) return;  // wave uniform
-        unsigned alo = 0, ahi = 0;
+    for (unsigned t = 0; t < n_t; ++t) {
+        const v4u e = e_next;
+        const unsigned lv = (unsigned)(~c_next >> ((bj & 15) * 4)) & 15u;
+        const v2q mq = ~m_next;
+        const unsigned m0 = (unsigned)mq.x, m1 = (unsigned)(mq.x >> 32), m2 = (unsigned)mq.y, m3 = (unsigned)(mq.y >> 32);
+        const u64 step = t + 1 < n_t ? 512 : 0;  // (the last tile re-reads itself: harmless, keeps every request unconditional)
+        __syncthreads();  // the previous tile's lookups are done
+        {
+            const AftLimbs q0 = aft_limbs(e.x, lv & 1), q1 = aft_limbs(e.y, lv & 2), q2 = aft_limbs(e.z, lv & 4), q3 = aft_limbs(e.w, lv & 8);
+            AftLimbs tv[16];
+            tv[0] = AftLimbs{0, 0}; tv[1] = q0; tv[2] = q1; tv[3] = q0 + q1;
+            tv[4] = q2; tv[5] = q2 + q0; tv[6] = q2 + q1; tv[7] = q2 + tv[3];
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
+            for (int b = 0; b < 8; ++b) tv[8 + b] = q3 + tv[b];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned y = k == 0 ? x[d] << 8 : x[d] >> (8 * k - 8);
-                const int p = 4 * d + k;
-                const u64 ev = *reinterpret_cast<const u64 *>(tb + ((y & 0xF00u) | sub_even) + p * 4096);
-                const u64 od = *reinterpret_cast<const u64 *>(tb + ((y & 0xF000u) | sub_odd) + p * 256);
-                alo += (unsigned)ev + (unsigned)od;
-                ahi += (unsigned)(ev >> 32) + (unsigned)(od >> 32);
+            for (int b = 1; b < 16; ++b) *reinterpret_cast<u64 *>(tb_w + b * w_stride) = (u64)tv[b].lo | ((u64)tv[b].hi << 32);
+            if (t == 0) *reinterpret_cast<u64 *>(tb_w) = 0ull;  // (entry 0 is zero in every tile)
+        }
+        af_thread += step / 8 * 64;  // (64 words of covered = 4,096 table values further on)
+        cov_thread += step / 8;
+        cov_lane += step / 8;
+        e_next = *reinterpret_cast<const v4u *>(af_thread);
+        c_next = *cov_thread;
+        m_next = *reinterpret_cast<const v2q *>(cov_lane);
+        __syncthreads();  // the tables stand
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            const v4u x = ring[u % D];
+            if ((unsigned)u < n_my) {  // wave uniform
+                const unsigned n_lane = __popc(x.x & m0) + __popc(x.y & m1) + __popc(x.z & m2) + __popc(x.w & m3);
+                if (__ballot(n_lane != 0) != 0) {  // wave uniform
+                    unsigned l = 0, h = ahi[u];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned y = k == 0 ? x[d] << 8 : x[d] >> (8 * k - 8);
+                            const int p = 4 * d + k;
+                            const u64 ev = *reinterpret_cast<const u64 *>(tb + ((y & 0xF00u) | sub_even) + p * 4096);
+                            const u64 od = *reinterpret_cast<const u64 *>(tb + ((y & 0xF000u) | sub_odd) + p * 256);
+                            l += (unsigned)ev + (unsigned)od;
+                            h += (unsigned)(ev >> 32) + (unsigned)(od >> 32);
+                        }
+                    }
+                    ahi[u] = h + (l >> UTM_AFT_LIMB);
+                    alo[u] += l & ((1u << UTM_AFT_LIMB) - 1);  // (below 2^29 after 16 tiles)
+                    acn[u] += n_lane;
+                }
+            }
+            pa[u] += step;
+            const int v = (u + D) % MAXU;  // the slot's next occupant: unit u + D of this tile, or unit u + D - MAXU of the next (pa[] already advanced)
+            ring[u % D] = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(pa[v]));
+        }
+        if ((t + 1) % UTM_AFT_RUN != 0 && t + 1 != n_t) continue;
+        // every UTM_AFT_RUN tiles, and at the end: half-wave sums and the atomics.  hi < 2^31 + 2^12 per lane: its
+        // 32-lane sum goes in two pieces.
+#pragma unroll
+        for (int u = 0; u < MAXU; ++u) {
+            if ((unsigned)u >= n_my) break;  // wave uniform
+            const bool mine = lo + 2 * (wave + NW * u) + half < hi;
+            const unsigned l = mine ? alo[u] & ((1u << UTM_AFT_LIMB) - 1) : 0u, h = mine ? ahi[u] + (alo[u] >> UTM_AFT_LIMB) : 0u, c = mine ? acn[u] : 0u;
+            alo[u] = ahi[u] = acn[u] = 0;
+            const unsigned n = half_sum32(c);
+            const unsigned tlo = half_sum32(l), th0 = half_sum32(h & 0xFFFFu), th1 = half_sum32(h >> 16);
+            if (sub == 31 && n) {
+                const unsigned s = s_of[wave][u][half];
+                atomicAdd(&cnt[s], (u64)n);
+                atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), ((((u64)th1 << 16) + th0) << UTM_AFT_LIMB) + tlo);
             }
         }
-        ahi += alo >> UTM_AFT_LIMB;  // lane: lo < 2^26, hi < 2^27 + 32 -- the 32-lane sums below stay inside 32 bits
-        alo &= (1u << UTM_AFT_LIMB) - 1;
-        if (!valid) alo = ahi = 0;  // (a tail half read something else)
-        const unsigned n = half_sum32(n_lane);
-        const unsigned tlo = half_sum32(alo), thi = half_sum32(ahi);
-        if (sub == 31 && n) {
-            atomicAdd(&cnt[s], (u64)n);
-            atomicAdd(reinterpret_cast<u64 *>(&afsum[s]), ((u64)thi << UTM_AFT_LIMB) + tlo);
-        }
-    };
-    for (unsigned k = wave; k < n_units; k += 2 * U * NW) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) request(k + (U + u) * NW, sb[u], xb[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) walk(k + u * NW, sa[u], xa[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) request(k + (2 * U + u) * NW, sa[u], xa[u]);
-#pragma unroll
-        for (int u = 0; u < U; ++u) walk(k + (U + u) * NW, sb[u], xb[u]);
     }
 }
 

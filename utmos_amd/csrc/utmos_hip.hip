@@ -122,7 +122,7 @@ static int rccl_load()
 struct Tune {
     int target_wgs, min_wgs, min_wgs_big, tile_steps, nt_loads, nt_min_mb;  // scoring grid shape
     int fuse_pick, pick_threads, batch;                                      // pick placement, host sync distance
-    int af_steps, af_target_wgs, af_tables, chain_pick, af_verify, af_record, af_defer; // AF kernels
+    int af_steps, af_target_wgs, af_tables, af_table_run, af_table_wgs_per_cu, chain_pick, af_verify, af_record, af_defer; // AF kernels
     double af_switch, af_dense_delta;
     int decr_first_batch, decr_interleaved;                                  // decremental mode
     int p2p_replicate, test_remote_winner;                                   // shards
@@ -149,6 +149,8 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_BATCH", batch, 0),
     UTM_KNOB_I("UTM_AF_STEPS", af_steps, 16),
     UTM_KNOB_I("UTM_AF_TARGET_WGS", af_target_wgs, 16384),
+    UTM_KNOB_I("UTM_AF_TABLE_RUN", af_table_run, 0),  // ... tiles per workgroup (0: by the grid, about UTM_AF_TABLE_WGS_PER_CU workgroups per CU)
+    UTM_KNOB_I("UTM_AF_TABLE_WGS_PER_CU", af_table_wgs_per_cu, 8),  // (10M x 2,504, same box: 2 -> 1,121 us, 4 -> 951, 8 -> 842, 12 -> 867, 16 -> 921, 24 -> 974)
     UTM_KNOB_I("UTM_AF_TABLES", af_tables, 1),  // full dense AF passes as table lookups (k_score_aft) where the table admits it; 0: k_score_afq
     UTM_KNOB_I("UTM_CHAIN_PICK", chain_pick, 1),
     UTM_KNOB_I("UTM_AF_VERIFY", af_verify, 1),
