@@ -242,6 +242,7 @@ static LoopShape loop_shape(utm_ctx *c, int af = 0)
         // +22 %, 24 tiles +7 % / +6 %, 28 tiles . / -1 %, 31 tiles -1.5 % / -5 %; 16 KiB tiles (3M x 640) +2 % / -13 %;
         // 64 KiB tiles (10M x 313) -50 % / -51 %.
         if (af && tn.persist_tile_kib <= 0 && (steps > 8 || tiles > (u64)std::max(1, tn.persist_af_max_tiles))) break;
+        if (af && steps > 32) break;  // (64 KiB tiles with the AF forms' second tile: two waves per SIMD, half the launches' rate -- not even built)
         // tiles of several batches only pay where the launch per iteration is weak -- few samples, tall columns (10M x 313:
         // +12 %); with 2,504 samples they lose ~10 % to the one-batch tile at equal height (1.1M: 0.70 against 0.79) and
         // are level with the launches at best (3M: +2 % / -3.4 %)
@@ -339,8 +340,8 @@ static int enqueue_loop(utm_ctx *c, const LoopShape &sh, int k_batch, int af = 0
     case 32: UTM_LAUNCH_LOOP2(16, false); break;
     case 65: UTM_LAUNCH_LOOP2(32, true); break;
     case 64: UTM_LAUNCH_LOOP2(32, false); break;
-    case 129: UTM_LAUNCH_LOOP2(64, true); break;
-    default: UTM_LAUNCH_LOOP2(64, false); break;
+    case 129: UTM_LAUNCH_LOOP(64, true, 0); break;  // (integer only: loop_shape)
+    default: UTM_LAUNCH_LOOP(64, false, 0); break;
     }
 #undef UTM_LAUNCH_LOOP2
 #undef UTM_LAUNCH_LOOP
