@@ -215,11 +215,10 @@ static LoopShape loop_shape(utm_ctx *c, int af = 0)
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][0], k_loop_int<8, true, 1>, UTM_LOOP_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][1], k_loop_int<16, true, 1>, UTM_LOOP_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][2], k_loop_int<32, true, 1>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[1][3], k_loop_int<64, true, 1>, UTM_LOOP_THREADS, 0);
+        occ_all[1][3] = occ_all[2][3] = 0;  // (the AF forms are not built for 64 KiB tiles)
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[2][0], k_loop_int<8, true, 2>, UTM_LOOP_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[2][1], k_loop_int<16, true, 2>, UTM_LOOP_THREADS, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[2][2], k_loop_int<32, true, 2>, UTM_LOOP_THREADS, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_all[2][3], k_loop_int<64, true, 2>, UTM_LOOP_THREADS, 0);
         cus = prop.multiProcessorCount;
         if (getenv("UTM_VERBOSE"))
             fprintf(stderr, "libutmos_hip: k_loop_int occupancy query: %d / %d / %d / %d (AF form %d / %d / %d / %d, with intervals %d / %d / %d / %d) blocks of %d threads per CU (8 / 16 / 32 / 64 KiB tile), %d CUs\n",
