@@ -9,7 +9,7 @@ A *step* is one full `select all` run of the greedy loop (utmos/select.py:69-112
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W          # one rank per GPU; samples sharded over the ranks
 
-N = 1, default workload: after the headline the other single-GPU BASELINE configurations run one step each (cfg3
+N = 1, default workload: after the headline the other single-GPU BASELINE configurations run a few timed steps each (cfg3
 `--af` float32 and the same with the reference's in-memory float64 values, cfg1 chr22-sized, one rank's share of cfg4
 for 20 iterations, cfg5's 156 GB for 10) and are attached under `also`, each with its own it/s, bytes and roofline fraction.
 
@@ -49,7 +49,7 @@ WORKLOADS = {
     "cfg5": ("500M x 2,504 in chunks of 50M, first 10 iterations",
              dict(n_var=500_000_000, n_samp=2504, select=10, chunk_vars=50_000_000)),
 }
-ALSO = ("cfg3", "af64", "cfg1", "cfg1af", "cfg1af64", "cfg4rank", "cfg5")   # attached to the default single-GPU line, one step each
+ALSO = ("cfg3", "af64", "cfg1", "cfg1af", "cfg1af64", "cfg4rank", "cfg5")   # attached to the default single-GPU line, 1-5 timed steps each
 
 
 def parse():
@@ -559,7 +559,7 @@ def main():
     if rank != 0:
         return
 
-    # N = 1, default workload: the other single-GPU BASELINE configurations, one step each
+    # N = 1, default workload: the other single-GPU BASELINE configurations, a few steps each
     also = None
     if world == 1 and not args.explicit_shape and not args.no_also and not args.force_comm and not args.force_mailboxes:
         also = {}
@@ -571,12 +571,14 @@ def main():
                 with m2:
                     k2 = select_count(s2)
                     cal2 = m2.stream_calibration(20 if s2["n_var"] * s2["n_samp"] < 4e11 else 3)
-                    r2 = timed_steps(m2, k2, 1, 1 if name in ("cfg1", "cfg1af", "cfg1af64", "cfg3", "af64") else 0, lambda v: v)
+                    # timed steps per leg: 5 where a step is under 0.1 s, 2 at 10M x 2,504, 1 for the 78 / 156 GB shapes
+                    n2 = 5 if name in ("cfg1", "cfg1af", "cfg1af64") else 2 if name in ("cfg3", "af64") else 1
+                    r2 = timed_steps(m2, k2, n2, 1 if n2 > 1 else 0, lambda v: v)
                     roof2 = roofline_pass(m2, k2, s2["af"])
                     if roof2 is not None:
                         roof2["stream_calibration_gbps"] = cal2
                         roof2["frac_of_stream"] = roof2["achieved"] / cal2
-                also[name] = summarize(s2, WORKLOADS[name][0], 1, 1, r2, roof2, t2)
+                also[name] = summarize(s2, WORKLOADS[name][0], 1, n2, r2, roof2, t2)
             except device.nat.NativeError as exc:      # e.g. a GPU with less HBM than the 156 GB of cfg5
                 also[name] = {"workload": WORKLOADS[name][0], "error": str(exc)}
 

@@ -314,7 +314,7 @@ def test_bench_line_contract_single_gpu(tmp_path):
 
 
 def test_bench_default_line_carries_every_single_gpu_config(tmp_path):
-    """The driver's plain `bench.py` invocation (no shape flags): the cfg2 headline plus one step each of cfg3, cfg1,
+    """The driver's plain `bench.py` invocation (no shape flags): the cfg2 headline plus a few steps each of cfg3, cfg1,
     float64 AF, one rank's share of cfg4 and cfg5 under `also`, each with its own bytes and roofline fraction."""
     import json
     import subprocess
