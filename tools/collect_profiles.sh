@@ -27,10 +27,6 @@ echo "== SQ / TCC counters of the integer scoring kernel (first 120 iterations o
 (cd $R && python3 tools/pmc_sq.py ${tag}_cfg2 k_score_int -- --steps 1 --warmup 0 --select 120 --no-cpu-baseline --no-roofline-pass --no-also --no-calibration --pmc-traffic off > /dev/null 2>&1)
 (cd $R && python3 tools/pmc_sq.py ${tag}_cfg1 k_loop_int -- --workload cfg1 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline-pass --no-calibration --pmc-traffic off > /dev/null 2>&1)
 cp $R/profiles/${tag}_cfg2_pmc_sq.json $R/profiles/${tag}_cfg1_pmc_sq.json $out/ 2>/dev/null
-echo "== the full dense AF pass: table lookups (k_score_aft) against the bit walk (k_score_afq), cfg3 and 500M x 2,504; SQ counters of k_score_aft"
-(cd $R && { echo "10M x 2,504 (cfg3):"; bash tools/ab_af_first_pass.sh 10000000 2504 | grep "k_score_af[qt]"; echo "500M x 2,504 in 10 chunks of 50M (one launch per chunk):"; bash tools/ab_af_first_pass.sh 500000000 2504 --chunk-vars 50000000 | grep "k_score_af[qt]"; } > $out/${tag}_af_first_pass_tables_vs_bitwalk_raw.txt 2>&1)
-(cd $R && python3 tools/pmc_sq.py ${tag}_cfg3_aft k_score_aft -- --af --select 2 --steps 2 --warmup 0 --no-cpu-baseline --no-roofline-pass --no-calibration --no-also --pmc-traffic off > /dev/null 2>&1)
-cp $R/profiles/${tag}_cfg3_aft_pmc_sq.json $out/ 2>/dev/null
 echo "== per-iteration cost of every exchange form, from one GPU (10M x 313 = one rank's share of cfg2 at 8 GPUs; cfg2)"
 (cd $R && AB_REPS="1 2" bash tools/exchange_table.sh "--n-var 10000000 --n-samp 313" > $out/${tag}_exchange_cost_one_gpu_shard_shape_10Mx313.txt 2>&1)
 (cd $R && AB_REPS=1 AB_STEPS=2 bash tools/exchange_table.sh "--n-var 10000000 --n-samp 2504" > $out/${tag}_exchange_cost_one_gpu_cfg2.txt 2>&1)
