@@ -203,6 +203,11 @@ int utm_run(utm_ctx *ctx, int64_t k_max, int64_t *idx_out, int64_t *new_out, dou
 /* Scores of the NEXT iteration without selecting: counts[n_local] (new variants per local sample,
  * 0 for non-selectable) and final scores[n_local].  Either may be NULL.  Parity/debug aid. */
 int utm_peek_scores(utm_ctx *ctx, int64_t *counts, double *scores);
+/* AF modes in fixed point (utm_stats.af_fixed_point != 0): the same, from the PARALLEL full pass the loop's first iteration
+ * runs (k_score_aft / k_score_afq / k_score_afs) instead of the sequential chains -- scores[s] = int64 sum * 2^-q (* weight),
+ * which IS the reference's float64 sum wherever the sums are exact (float32 AF, lossless unit, below 2^53 units).
+ * UTM_ESTATE otherwise.  Parity/debug aid: what the tests compare the first pass with. */
+int utm_peek_estimates(utm_ctx *ctx, int64_t *counts, double *scores);
 /* Current covered mask of a chunk (all pending updates applied), ceil(n_var/64) words. */
 int utm_get_covered(utm_ctx *ctx, int32_t chunk, uint64_t *out);
 int utm_get_stats(utm_ctx *ctx, utm_stats *out);

@@ -44,6 +44,40 @@ def test_select_all_checks_every_samples_first_pass_sum(dev, tables, n_samp, mon
     assert st["af_table_passes"] == (1 if tables == "1" and n_samp - 2 >= 64 else 0), st
 
 
+@pytest.mark.parametrize("tables", ["1", "0"])
+@pytest.mark.parametrize("shape", [(2048 * 5 + 777, 131), (4096 * 9, 256), (4096 * 3 + 1, 513)])
+def test_first_pass_of_every_sample_against_the_oracle(dev, tables, shape, monkeypatch):
+    """utm_peek_estimates = the parallel full pass: counts and (float32 AF, exact range) float64 sums of ALL samples."""
+    monkeypatch.setenv("UTM_AF_TABLES", tables)
+    monkeypatch.setenv("UTM_AF_TABLE_RUN", "2")
+    n_var, n_samp = shape
+    rng = np.random.default_rng(n_samp)
+    dense = ou.random_dense(rng, n_var, n_samp)
+    af = _af_of(dense, n_samp, "f32")
+    af[::41] = 0.0
+    state = np.ones(n_samp, np.uint8)
+    state[7] = 2
+    state[n_samp // 2] = 0
+    w = rng.choice([0.5, 1.0, 3.0], n_samp)
+    cols = ou.npo.pack_columns(dense)
+    with dev.DeviceMatrix(n_samp) as m:
+        c = m.add_chunk(n_var)
+        m.upload_columns(c, cols)
+        m.set_af(c, af)
+        m.set_state(state)
+        m.set_weights(w)
+        cnt, score = m.peek_estimates()
+        st = m.stats()
+        rows = m.run(5)                          # the loop still starts from scratch afterwards
+    _, exp_cnt, exp_score = ou.c_score(cols, n_var, state, w, af)
+    sel = state == 1
+    assert cnt[sel].tolist() == exp_cnt[sel].tolist() and (cnt[~sel] == 0).all()
+    assert score[sel].tolist() == exp_score[sel].tolist()
+    assert st["af_table_passes"] == (1 if tables == "1" else 0), st
+    exp = ou.c_greedy(cols, n_var, state, w, af, k_max=5)
+    assert rows[0].tolist() == exp[0].tolist() and rows[2].tolist() == exp[2].tolist()
+
+
 @pytest.mark.parametrize("tables", ["1", "0", "run3", "run40"])
 @pytest.mark.parametrize("kind", ["f32", "f64", "f32_chunks", "f32_weights"])
 def test_runs_with_the_table_pass(dev, tables, kind, monkeypatch):

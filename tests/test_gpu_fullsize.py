@@ -91,6 +91,12 @@ def test_cfg3_full_size_rows_against_the_oracle(dev, af_dtype):
         m.synth_fill(c, seed=0)
         m.set_af(c, af)
         cols = download(m, c)
+        if af_dtype == "f32":
+            # the parallel first pass itself (k_score_aft: table lookups): every sample's count and exact sum
+            counts, est = m.peek_estimates()
+            _, cnt0, sc0 = ou.c_score(cols, n_var, np.ones(n_samp, np.uint8), af=af, omp=True)
+            assert (counts == cnt0).all() and (est == sc0).all()
+            assert m.stats()["af_table_passes"] == 1
         rows = m.run(n_samp)
         assert len(rows[0]) == n_samp
         exp = ou.c_greedy(cols, n_var, np.ones(n_samp, np.uint8), af=af, k_max=8, omp=True)
@@ -138,7 +144,8 @@ def bench_host_mem_gb():
 def test_cfg5_full_size_counts_against_the_oracle(dev):
     """BASELINE configs[4], 500M x 2,504 in ten HBM-resident chunks (156 GB): per-chunk oracle counts (one chunk on the
     host at a time), summed over the ten chunks, against utm_peek_scores for iteration 0 and for the state after 12
-    selections; the oracle's argmax over the sums is the GPU run's row."""
+    selections; the oracle's argmax over the sums is the GPU run's row.  Then the first iteration of an `--af` run over
+    the same 500M rows: the parallel first pass's counts and exact float32-AF sums of all samples (utm_peek_estimates)."""
     free, total = dev.nat.device_memory(0)
     if total < 200e9:
         pytest.skip("needs an MI355X-sized HBM (156 GB matrix)")
@@ -152,14 +159,28 @@ def test_cfg5_full_size_counts_against_the_oracle(dev):
         assert len(rows[0]) == k
         states = [np.ones(n_samp, np.uint8), state_after(n_samp, rows[0][:12])]
         sums = [np.zeros(n_samp, np.int64) for _ in states]
+        afs, af_sum = [], np.zeros(n_samp, np.float64)
         for c in range(10):
             cols = download(m, c)
             for st, acc in zip(states, sums):
                 _, cnt, _ = ou.c_score(cols, chunk_vars, st, omp=True)     # covered = OR of the used samples' columns of THIS chunk
                 acc += cnt
+            # ... and the first iteration of an --af run over the same chunks (float32 AF: every partial sum is exact, so the
+            # chunks' float64 sums add up to the reference's sum over all 500M rows)
+            # (AF on a 2^-16 grid: a sample's sum over 500M rows then stays below 2^53 units, every float64 add is exact)
+            af_c = dev.synth_host(0, chunk_vars, n_samp, first_var_global=c * chunk_vars, want_cols=False)[1]
+            afs.append((np.maximum(np.rint(af_c.astype(np.float64) * 65536.0), 1.0) / 65536.0).astype(np.float32))
+            af_sum += ou.c_score(cols, chunk_vars, states[0], af=afs[-1], omp=True)[2]
             del cols
         for st, acc, at in zip(states, sums, (0, 12)):
             m.set_state(st)
             counts, scores = m.peek_scores()
             assert (counts == acc).all() and (scores == acc).all()
             assert int(np.argmax(acc)) == rows[0][at] and acc.max() == rows[1][at]      # first maximum = np.argmax (select.py:48)
+        # the parallel first AF pass at this size (ten k_score_aft launches): all 2,504 counts and exact sums
+        for c in range(10):
+            m.set_af(c, afs[c])
+        m.set_state(states[0])
+        counts, est = m.peek_estimates()
+        assert (counts == sums[0]).all() and (est == af_sum).all()
+        assert m.stats()["af_table_passes"] == 10

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "utm_step": [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_double)],
     "utm_run": [_P, _I64, _P, _P, _P, ctypes.POINTER(_I64)],
     "utm_peek_scores": [_P, _P, _P],
+    "utm_peek_estimates": [_P, _P, _P],
     "utm_get_covered": [_P, _I32, _P],
     "utm_get_stats": [_P, ctypes.POINTER(Stats)],
     "utm_set_profile": [_P, _I32],

@@ -874,6 +874,29 @@ extern "C" int utm_peek_scores(utm_ctx *c, int64_t *counts, double *scores)
     return UTM_OK;
 }
 
+extern "C" int utm_peek_estimates(utm_ctx *c, int64_t *counts, double *scores)
+{
+    CTX(c);
+    TRY(ensure_prepared(c));
+    if (c->af_mode == UTM_AF_NONE || !c->af_fixed) return fail(UTM_ESTATE, "estimates exist only for AF scores in fixed point");
+    c->keep_valid = false;  // a full parallel pass, the pending winner applied
+    TRY(enqueue_score(c, /*force_sequential=*/false, false, nullptr, /*by_sample=*/true));
+    Scratch<i64> d_counts;
+    Scratch<double> d_scores;
+    HIP_TRY(d_counts.alloc(c->n_local));
+    HIP_TRY(d_scores.alloc(c->n_local));
+    PickArgs pa = pick_args(c);
+    hipLaunchKernelGGL(k_final_scores, dim3((c->n_local + 255) / 256), dim3(256), 0, c->stream, pa, d_counts.p, d_scores.p);
+    (void)hipMemsetAsync(c->d_cnt, 0, (size_t)c->n_local * 8, c->stream);
+    (void)hipMemsetAsync(c->d_afsum, 0, (size_t)c->n_local * 8, c->stream);
+    c->keep_valid = false;  // (the accumulators were borrowed: the next iteration re-scores in full)
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && counts) e = copy_sync(c, counts, d_counts.p, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && scores) e = copy_sync(c, scores, d_scores.p, (size_t)c->n_local * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail(UTM_EHIP, "peek: %s", hipGetErrorString(e));
+    return UTM_OK;
+}
+
 static int flush_pending(utm_ctx *c)
 {
     for (auto &ch : c->chunks)

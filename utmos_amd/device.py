@@ -152,6 +152,13 @@ class DeviceMatrix:
         nat.check(nat.lib().utm_peek_scores(self._h, _ptr(counts), _ptr(scores)))
         return counts, scores
 
+    def peek_estimates(self):
+        """AF in fixed point: counts and scores of the next iteration from the parallel full pass (not the chains)."""
+        counts = np.zeros(self.n_local, dtype=np.int64)
+        scores = np.zeros(self.n_local, dtype=np.float64)
+        nat.check(nat.lib().utm_peek_estimates(self._h, _ptr(counts), _ptr(scores)))
+        return counts, scores
+
     def covered(self, chunk):
         out = np.zeros((self.chunk_vars[chunk] + 63) // 64, dtype=np.uint64)
         nat.check(nat.lib().utm_get_covered(self._h, chunk, _ptr(out)))
