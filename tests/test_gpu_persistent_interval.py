@@ -197,7 +197,10 @@ def test_af_forms_with_forced_larger_tiles(dev, tile_kib, dtype, monkeypatch):
     af = quantized_af(rng, n_var, n_samp) if dtype == "f64" else (rng.integers(1, 2 * n_samp, n_var) / (2.0 * n_samp)).astype(np.float32)
     cols = npo.pack_columns(dense)
     st = run_af(dev, cols, n_var, n_samp, af)
-    assert st["persist_iterations"] > 0.5 * st["iterations"], st
+    if tile_kib == "64":       # (not built for the AF forms: two waves per SIMD, half the launches' rate -- the launches take the run)
+        assert st["persist_iterations"] == 0, st
+    else:
+        assert st["persist_iterations"] > 0.5 * st["iterations"], st
 
 
 @pytest.mark.parametrize("seed", range(16))
