@@ -145,7 +145,7 @@ def test_cfg5_full_size_counts_against_the_oracle(dev):
     """BASELINE configs[4], 500M x 2,504 in ten HBM-resident chunks (156 GB): per-chunk oracle counts (one chunk on the
     host at a time), summed over the ten chunks, against utm_peek_scores for iteration 0 and for the state after 12
     selections; the oracle's argmax over the sums is the GPU run's row.  Then the first iteration of an `--af` run over
-    the same 500M rows: the parallel first pass's counts and exact float32-AF sums of all samples (utm_peek_estimates)."""
+    the same 500M rows: the parallel first pass's counts and exact float32-AF sums of every eighth sample (utm_peek_estimates)."""
     free, total = dev.nat.device_memory(0)
     if total < 200e9:
         pytest.skip("needs an MI355X-sized HBM (156 GB matrix)")
@@ -160,6 +160,8 @@ def test_cfg5_full_size_counts_against_the_oracle(dev):
         states = [np.ones(n_samp, np.uint8), state_after(n_samp, rows[0][:12])]
         sums = [np.zeros(n_samp, np.int64) for _ in states]
         afs, af_sum = [], np.zeros(n_samp, np.float64)
+        af_state = np.full(n_samp, 2, np.uint8)          # the AF leg scores 313 samples (the oracle's float adds are the test's time)
+        af_state[::8] = 1
         for c in range(10):
             cols = download(m, c)
             for st, acc in zip(states, sums):
@@ -170,17 +172,20 @@ def test_cfg5_full_size_counts_against_the_oracle(dev):
             # (AF on a 2^-16 grid: a sample's sum over 500M rows then stays below 2^53 units, every float64 add is exact)
             af_c = dev.synth_host(0, chunk_vars, n_samp, first_var_global=c * chunk_vars, want_cols=False)[1]
             afs.append((np.maximum(np.rint(af_c.astype(np.float64) * 65536.0), 1.0) / 65536.0).astype(np.float32))
-            af_sum += ou.c_score(cols, chunk_vars, states[0], af=afs[-1], omp=True)[2]
+            _, af_cnt_c, af_sc_c = ou.c_score(cols, chunk_vars, af_state, af=afs[-1], omp=True)
+            af_sum += af_sc_c
+            af_cnt = af_cnt_c if c == 0 else af_cnt + af_cnt_c
             del cols
         for st, acc, at in zip(states, sums, (0, 12)):
             m.set_state(st)
             counts, scores = m.peek_scores()
             assert (counts == acc).all() and (scores == acc).all()
             assert int(np.argmax(acc)) == rows[0][at] and acc.max() == rows[1][at]      # first maximum = np.argmax (select.py:48)
-        # the parallel first AF pass at this size (ten k_score_aft launches): all 2,504 counts and exact sums
+        # the parallel first AF pass at this size (ten k_score_aft launches): the 313 selectable samples' counts and exact sums
         for c in range(10):
             m.set_af(c, afs[c])
-        m.set_state(states[0])
+        m.set_state(af_state)
         counts, est = m.peek_estimates()
-        assert (counts == sums[0]).all() and (est == af_sum).all()
+        sel = af_state == 1
+        assert (counts[sel] == af_cnt[sel]).all() and (counts[~sel] == 0).all() and (est == af_sum).all()
         assert m.stats()["af_table_passes"] == 10
