@@ -51,7 +51,7 @@
  *                             batch of iterations as ONE persistent
  *                             launch (k_loop_int: workers keep their covered tile in LDS, the picker's record replaces the kernel
  *                             boundary, two batches per wave run ahead across the hand-off)
- *   UTM_PERSIST_MAX_MB (600), UTM_PERSIST_MAX_SAMPLES (2560), UTM_PERSIST_MAX_TILES (32)   largest matrix / sample count run that
+ *   UTM_PERSIST_MAX_MB (560), UTM_PERSIST_MAX_SAMPLES (2560), UTM_PERSIST_MAX_TILES (32)   largest matrix / sample count run that
  *                             way, and the tile count the tile size (8 / 16 / 32 / 64 KiB) is chosen for; UTM_PERSIST_TILE_KIB forces one;
  *                             tiles above 8 KiB (columns taller than 32 tiles) only up to UTM_PERSIST_TALL_MAX_SAMPLES (640) samples
  *   UTM_PERSIST_WGS_PER_CU (0 = what the occupancy query allows)   resident 512-thread blocks per CU the grid is sized for

@@ -163,7 +163,7 @@ static const KnobDef g_knobs[] = {
     UTM_KNOB_I("UTM_P2P_REPLICATE", p2p_replicate, 1),
     UTM_KNOB_I("UTM_TEST_REMOTE_WINNER", test_remote_winner, 0),
     UTM_KNOB_I("UTM_PERSISTENT", persistent, 1),
-    UTM_KNOB_I("UTM_PERSIST_MAX_MB", persist_max_mb, 600),  // (2,504 samples, same box, against the launches with 8 KiB tiles: +5 % at 0.47 GB, +0.5 % at 0.63 GB, -3.4 ... +2 % at 0.94 GB, -2.6 % at 1.56 GB; with their 16 KiB tiles from 1.8M variants up the launches lead by 2 % at 0.63 GB)
+    UTM_KNOB_I("UTM_PERSIST_MAX_MB", persist_max_mb, 560),  // (2,504 samples, same box, against the launches with 8 KiB tiles: +5 % at 0.47 GB, +0.5 % at 0.63 GB, -3.4 ... +2 % at 0.94 GB, -2.6 % at 1.56 GB; with their 16 KiB tiles from 1.8M variants up the launches lead by 2 % at 0.63 GB = 599 MiB, so the limit sits below that)
     UTM_KNOB_I("UTM_PERSIST_WGS_PER_CU", persist_wgs_per_cu, 0),
     UTM_KNOB_I("UTM_PERSIST_MAX_TILES", persist_max_tiles, 32),
     UTM_KNOB_I("UTM_PERSIST_TILE_KIB", persist_tile_kib, 0),
