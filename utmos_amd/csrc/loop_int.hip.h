@@ -135,7 +135,7 @@ struct LoopCand {  // interval form: a sample whose score interval reaches the b
 #define UTM_LOOP_IV_BLOCKS 4  // interval form: waves per SIMD the kernel is compiled for (a block is two waves per SIMD: 3 would leave ONE block per CU)
 #endif
 #define UTM_LOOP_CHAIN_CAP 512  // addends of one chain inside the launch (one per thread of the chainer); more: the host's launches take the iteration
-#define UTM_LOOP_REQ_SPINS (1u << 18)     // x s_sleep(4): ~0.1 s before the picker gives up on the chainer (the iteration then goes to the host)
+#define UTM_LOOP_REQ_SPINS (1u << 16)     // x s_sleep(4): ~25 ms before the picker gives up on the chainer (the iteration then goes to the host); a chain takes tens of us
 #define UTM_LOOP_CHAINER_IDLE (1u << 22)  // idle polls (~0.5 us each) before the chainer takes the launch for lost
 struct LoopPickLds {
     IntCand wbest[UTM_LOOP_WAVES];
